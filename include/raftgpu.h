@@ -1,0 +1,250 @@
+/*
+ * raftgpu.h -- C ABI of the batched lockstep Raft engine for MI355X (gfx950).
+ *
+ * One engine advances n_groups independent Raft replica groups of n_peers
+ * peers each in discrete 10 ms ticks.  Every (group, peer) pair is a drop-in
+ * for one instance of the reference peer (reference: src/raft/raft.go:57-86)
+ * and is driven through the reference's own verbs:
+ *
+ *   Make        src/raft/raft.go:700   -> rg_create / rg_restart
+ *   Start       src/raft/raft.go:344   -> rg_start / rg_start_batch
+ *   GetState    src/raft/raft.go:90    -> rg_get_state
+ *   Kill        src/raft/raft.go:377   -> rg_crash
+ *   ApplyMsg    src/raft/raft.go:42    -> rg_drain_applied
+ *   persist / readPersist  src/raft/raft.go:107,129 and the Persister of
+ *               src/raft/persister.go:20-70 -> rg_snapshot_export/import
+ *   RequestVote / AppendEntries handlers src/raft/raft.go:200,270
+ *                                      -> rg_rpc_request_vote / rg_rpc_append_entries
+ *   harness verbs connect/disconnect/crash1/start1 src/raft/config.go:99-278
+ *                                      -> rg_set_connected / rg_crash / rg_restart
+ *
+ * All entry points are extern "C", take plain pointers and sizes, return an
+ * int status (0 = ok, <0 = error) and never abort.  Buffers are allocated by
+ * the caller.  One mutex inside the engine serialises calls, so concurrent
+ * callers (goroutines behind cgo) are safe.  There is no CPU fallback: every
+ * call fails with RG_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef RAFTGPU_H
+#define RAFTGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- lockstep time base (all reference timing literals are multiples of
+ * these; src/raft/raft.go:421,524,532-534,567,665,667,675) ---------------- */
+#define RG_TICK_MS            10   /* one tick of simulated time               */
+#define RG_ELECTION_PERIOD     5   /* election loop sleeps 50 ms  (:667)        */
+#define RG_ELECTION_LEADER_EXTRA 1 /* +10 ms when it saw state==2 (:665)        */
+#define RG_MONITOR_POLL        2   /* leader loop idle sleep 20 ms (:524)       */
+#define RG_HB_IDLE_MS        100   /* heartbeat gate, idle        (:421)        */
+#define RG_HB_BACKLOG_MS      50   /* heartbeat gate, uncommitted (:421)        */
+#define RG_CANDIDATE_WINDOW_MS 1000/* timeout while candidate     (:567)        */
+#define RG_TIMEOUT_BASE_MS   500   /* nextRandom(): Intn(600)+500 (:532-534)    */
+#define RG_TIMEOUT_SPAN_MS   600
+#define RG_MAX_PEERS           8
+
+/* ---- status codes ------------------------------------------------------ */
+#define RG_OK            0
+#define RG_ERR_ARG      -1   /* null pointer / bad size / bad config          */
+#define RG_ERR_HIP      -2   /* no device, launch or runtime failure          */
+#define RG_ERR_NOMEM    -3
+#define RG_ERR_RANGE    -4   /* group / peer / index out of range             */
+#define RG_ERR_STATE    -5   /* verb not legal in the peer's current state    */
+
+/* ---- peer roles (Raft.state, src/raft/raft.go:82) ----------------------- */
+#define RG_FOLLOWER  0
+#define RG_CANDIDATE 1
+#define RG_LEADER    2
+
+/* ---- safety / diagnostic flag bits, one word per group ------------------ */
+#define RG_FLAG_ELECTION_SAFETY     0x01u /* two connected leaders in one term (src/raft/config.go:317-320) */
+#define RG_FLAG_LOG_MATCHING        0x02u /* same index+term but different command or different predecessor */
+#define RG_FLAG_LEADER_COMPLETENESS 0x04u /* a live leader lacks an entry some peer already applied         */
+#define RG_FLAG_STATE_MACHINE       0x08u /* two peers applied different commands at one index (src/raft/config.go:177-182) */
+#define RG_FLAG_APPLY_ORDER         0x10u /* apply skipped an index (src/raft/config.go:184,191-193)        */
+#define RG_FLAG_REF_PANIC           0x20u /* state in which the reference would index past len(logs)        */
+#define RG_FLAG_LOG_OVERFLOW        0x40u /* a Start was refused because the fixed log capacity is full     */
+
+/* ---- counters (uint64 each) --------------------------------------------- */
+enum {
+  RG_C_GROUP_TICKS = 0,     /* groups x ticks advanced                                  */
+  RG_C_RPC_SENT,            /* every Call made, lost ones included (labrpc.go:153)       */
+  RG_C_RPC_DELIVERED,       /* handler ran on the target (labrpc.go:406)                 */
+  RG_C_RPC_REPLIED,         /* complete round trips                                      */
+  RG_C_RV_ROUNDS,           /* candidate rounds started (raft.go:565)                    */
+  RG_C_ELECTIONS_WON,       /* raft.go:641-658                                           */
+  RG_C_AE_ROUNDS,           /* leader replication rounds (raft.go:421-512)               */
+  RG_C_ENTRIES_STARTED,     /* accepted Start calls (raft.go:351-358)                    */
+  RG_C_ENTRIES_REPLICATED,  /* entries carried by successful AppendEntries               */
+  RG_C_ENTRIES_COMMITTED,   /* leader commitIndex advance (raft.go:409-411)              */
+  RG_C_ENTRIES_APPLIED,     /* ApplyMsg emitted (raft.go:677-685)                        */
+  RG_C_PERSISTS,            /* persist() calls (raft.go:107)                             */
+  RG_C_PERSIST_ENTRIES,     /* log entries newly copied into the snapshot arrays         */
+  RG_C_TIMEOUTS,            /* follower -> candidate transitions (raft.go:557-561)       */
+  RG_C_AE_CONFLICTS,        /* AppendEntries answered with a conflict hint (raft.go:303) */
+  RG_C_STEPDOWNS,           /* sender saw a higher term in a reply (raft.go:482,622)     */
+  RG_N_COUNTERS
+};
+
+/* ---- state fields for rg_read_state / rg_write_state -------------------- *
+ * Host layout: per-peer fields int32 [n_groups][n_peers]; per-group fields
+ * int32 [n_groups]; matrices int32 [n_groups][n_peers(owner)][n_peers];
+ * logs [n_groups][n_peers][log_cap] (int32 terms, uint64 commands).
+ * TIMER, HBTIMER, ELNEXT, MONNEXT, PARTNEXT are in ticks, TIMEOUT in ms.   */
+enum {
+  RG_F_TERM = 0, RG_F_VOTE, RG_F_STATE, RG_F_COMMIT, RG_F_APPLIED, RG_F_LOGLEN,
+  RG_F_TIMER, RG_F_TIMEOUT, RG_F_HBTIMER, RG_F_STOP, RG_F_CNT, RG_F_DEAD,
+  RG_F_RESTART, RG_F_FIRST, RG_F_MONALIVE, RG_F_ELNEXT, RG_F_MONNEXT,
+  RG_F_RNGCTR, RG_F_ROUNDSEQ, RG_F_SNAPHAS, RG_F_SNAPTERM, RG_F_SNAPVOTE,
+  RG_F_SNAPLEN, RG_F_CONNECTED, RG_F_SIDE,
+  RG_F_PEER_I32_END,                 /* fields above: int32 [G][P]           */
+  RG_F_APPLYHASH = 32,               /* uint64 [G][P]                        */
+  RG_F_NEXTINDEX = 40, RG_F_MATCHINDEX, /* int32 [G][P][P]                   */
+  RG_F_LOGTERM = 48, RG_F_SNAPLOGTERM,  /* int32 [G][P][L]                   */
+  RG_F_LOGCMD = 56, RG_F_SNAPLOGCMD,    /* uint64 [G][P][L]                  */
+  RG_F_STARTSEQ = 64, RG_F_PARTNEXT, RG_F_PARTEPOCH, RG_F_RECMAX, RG_F_GFLAGS, /* int32 [G] */
+  RG_F_APPLYREC = 72                 /* uint64 [G][L]                        */
+};
+
+/* ---- Start injection modes (device-side client workload) ---------------- */
+#define RG_START_ONE  0  /* first connected peer, in index order, that accepts (config.go:436-451) */
+#define RG_START_ALL  1  /* every live peer that claims leadership (test_test.go:697-703)          */
+
+/* Engine configuration: one plain struct across the ABI. */
+typedef struct rg_config {
+  int32_t  n_groups;            /* groups owned by this engine (this GPU's shard)                 */
+  int32_t  n_peers;             /* 2..8 peers per group                                           */
+  int32_t  log_cap;             /* fixed log capacity per peer, entry 0 is the sentinel           */
+  int32_t  device;              /* HIP device ordinal                                             */
+  int64_t  group_base;          /* global id of local group 0; all seeded streams key on global id */
+  uint64_t seed;
+  /* network model (labrpc.go:216-307) */
+  int32_t  req_drop_permille;   /* request lost before the handler runs   (:226)                  */
+  int32_t  reply_drop_permille; /* reply lost after the handler ran       (:273)                  */
+  int32_t  reply_delay_permille;/* long reordering: reply later than the 25 ms wait (:276)        */
+  /* client workload generated on the device */
+  int32_t  start_period;        /* ticks between Start injections, 0 = none                       */
+  int32_t  start_first_tick;
+  int32_t  start_max;           /* stop after this many accepted Starts per group                 */
+  int32_t  start_mode;          /* RG_START_ONE / RG_START_ALL                                    */
+  /* rolling partitions (kvraft/test_test.go:124-143): every part_period +
+   * hash % part_jitter ticks each peer is put on side hash & 1             */
+  int32_t  part_period;         /* 0 = none                                                       */
+  int32_t  part_jitter;
+  /* churn (test_test.go:893-919): every churn_period ticks, per group      */
+  int32_t  churn_period;        /* 0 = none                                                       */
+  int32_t  churn_disconnect_permille;
+  int32_t  churn_restart_permille;
+  int32_t  churn_crash_permille;
+  int32_t  reserved[3];
+} rg_config;
+
+typedef struct rg_engine rg_engine;
+
+/* RequestVoteArgs / Reply (src/raft/raft.go:161-177), fixed-width. */
+typedef struct rg_vote_args  { int32_t term, candidate, last_log_index, last_log_term; } rg_vote_args;
+typedef struct rg_vote_reply { int32_t term, granted; } rg_vote_reply;
+/* AppendEntriesArgs / Reply (src/raft/raft.go:179-195).  Entries of request i
+ * are entry_terms/entry_cmds[entry_off .. entry_off + n_entries).           */
+typedef struct rg_append_args {
+  int32_t term, leader, prev_log_index, prev_log_term, leader_commit, n_entries;
+  int64_t entry_off;
+} rg_append_args;
+typedef struct rg_append_reply { int32_t term, success, conflict_term, conflict_first_index; } rg_append_reply;
+/* ApplyMsg (src/raft/raft.go:42-46); CommandValid is always true here. */
+typedef struct rg_apply_msg { int64_t command_index; uint64_t command; } rg_apply_msg;
+/* One host command for rg_start_batch. */
+typedef struct rg_start_req { int32_t group, peer; uint64_t command; int32_t index, term, is_leader, pad; } rg_start_req;
+
+/* Library / device probe: number of usable gfx950 devices, or RG_ERR_HIP. */
+int rg_device_count(void);
+const char *rg_version(void);
+const char *rg_strerror(int status);
+
+/* Make (raft.go:700-731) for every peer of every group, all connected, tick 0. */
+int rg_create(const rg_config *cfg, rg_engine **out);
+int rg_destroy(rg_engine *e);
+/* Back to the state rg_create leaves (tick 0, empty persisters), same config. */
+int rg_reset(rg_engine *e);
+/* Launch on a caller-owned HIP stream (hipStream_t), NULL = the engine's own. */
+int rg_set_stream(rg_engine *e, void *hip_stream);
+
+/* Advance every group n_ticks ticks (election timers raft.go:536-669, leader
+ * loop :387-530, handlers :200-321, apply :672-688, persist :107-123) in ONE
+ * kernel launch; state stays resident in HBM between calls.  Asynchronous on
+ * the engine's stream; rg_sync waits. */
+int rg_step(rg_engine *e, int32_t n_ticks);
+int rg_sync(rg_engine *e);
+int rg_now(rg_engine *e, int64_t *tick);
+/* Wall time (ms) of the kernels launched by rg_step so far, from HIP events
+ * recorded on the launch stream, and the number of launches.  Synchronises. */
+int rg_step_time_ms(rg_engine *e, double *total_ms, int64_t *launches);
+
+/* Start (raft.go:344-364): index/term/is_leader as the reference returns them. */
+int rg_start(rg_engine *e, int32_t group, int32_t peer, uint64_t command,
+             int32_t *index, int32_t *term, int32_t *is_leader);
+int rg_start_batch(rg_engine *e, rg_start_req *reqs, int64_t n);
+/* GetState (raft.go:90-100). */
+int rg_get_state(rg_engine *e, int32_t group, int32_t peer, int32_t *term, int32_t *is_leader);
+
+/* Harness verbs (config.go:235-278, 99-127, 136-215).  rg_crash = crash1:
+ * disconnect, drop volatile state, keep the snapshot arrays.  rg_restart =
+ * start1: crash1, then Make + readPersist from the snapshot arrays; the peer
+ * stays disconnected until rg_set_connected, as in the harness. */
+int rg_set_connected(rg_engine *e, int32_t group, int32_t peer, int32_t connected);
+int rg_set_side(rg_engine *e, int32_t group, int32_t peer, int32_t side);
+int rg_crash(rg_engine *e, int32_t group, int32_t peer);
+int rg_restart(rg_engine *e, int32_t group, int32_t peer);
+/* Network.Reliable / LongReordering (labrpc.go:169-181), all groups. */
+int rg_set_unreliable(rg_engine *e, int32_t req_drop_permille,
+                      int32_t reply_drop_permille, int32_t reply_delay_permille);
+
+/* applyCh (raft.go:672-688): copies the ApplyMsgs the peer emitted since the
+ * last drain (after a restart the replay from index 1) into buf. */
+int rg_drain_applied(rg_engine *e, int32_t group, int32_t peer,
+                     rg_apply_msg *buf, int64_t cap, int64_t *n_out);
+
+/* Persister blob (persister.go:34-45): int32 term, int32 vote, int32 len,
+ * int32 0, then len x {int32 term, int32 0, uint64 command}.  Export with
+ * buf == NULL returns the size.  Import replaces the peer's snapshot arrays;
+ * it takes effect at the next rg_restart, like swapping the Persister. */
+int rg_snapshot_export(rg_engine *e, int32_t group, int32_t peer,
+                       void *buf, int64_t cap, int64_t *size_out);
+int rg_snapshot_import(rg_engine *e, int32_t group, int32_t peer,
+                       const void *buf, int64_t size);
+
+/* The reference's exported RPC handlers, batched: request i is handled by
+ * peer peers[i] of group groups[i]; requests to one peer are handled in
+ * array order.  Dead peers leave the reply untouched (raft.go:203,273). */
+int rg_rpc_request_vote(rg_engine *e, int64_t n, const int32_t *groups, const int32_t *peers,
+                        const rg_vote_args *args, rg_vote_reply *replies);
+int rg_rpc_append_entries(rg_engine *e, int64_t n, const int32_t *groups, const int32_t *peers,
+                          const rg_append_args *args, const int32_t *entry_terms,
+                          const uint64_t *entry_cmds, int64_t n_entries_total,
+                          rg_append_reply *replies);
+
+/* Bulk state access in the host layout given with the RG_F_* ids. */
+int rg_read_state(rg_engine *e, int32_t field, void *dst, int64_t dst_bytes);
+int rg_write_state(rg_engine *e, int32_t field, const void *src, int64_t src_bytes);
+/* One 64-bit digest per group over every Raft-visible word (scalars, the
+ * leader matrices, log and snapshot prefixes, apply digests). */
+int rg_state_hash(rg_engine *e, uint64_t *out, int64_t n_groups);
+
+int rg_counters(rg_engine *e, uint64_t *out /* RG_N_COUNTERS */);
+/* Full log-matching and leader-completeness scan; ORs into the group flags. */
+int rg_safety_check(rg_engine *e);
+/* out[0] = OR of all group flag words, out[1] = number of flagged groups. */
+int rg_safety_flags(rg_engine *e, uint32_t *out /* 2 */);
+/* Device addresses of the counter block (RG_N_COUNTERS x uint64) and of the
+ * flag summary (2 x uint32, refreshed by rg_safety_flags) for collectives
+ * that reduce them in place across GPUs. */
+int rg_device_buffers(rg_engine *e, void **counters_dev, void **flag_summary_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAFTGPU_H */

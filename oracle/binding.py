@@ -1,0 +1,143 @@
+"""ctypes handle on the CPU checker (oracle/libraft_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and
+by bench.py's cpu_baseline leg.  The product package never imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from raft_amd import _abi
+from raft_amd._abi import AppendArgs, AppendReply, VoteArgs, VoteReply, Config
+from raft_amd.engine import EngineBase
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libraft_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(HERE, "raft_oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "libraft_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+def load(path=None):
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    if path is None and os.path.isdir("/root/reference") is False and not os.path.exists(LIB):
+        raise RuntimeError("oracle library missing: " + LIB)
+    if path is None and not os.path.exists(LIB):
+        build()
+    lib = C.CDLL(path or LIB)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    P = C.POINTER
+    sig = {
+        "ro_create": ([P(Config)], vp), "ro_destroy": ([vp], None), "ro_reset": ([vp], None),
+        "ro_set_full_persist": ([vp, C.c_int], None),
+        "ro_step": ([vp, i32], C.c_int), "ro_step_mt": ([vp, i32, i32], C.c_int), "ro_now": ([vp], i64),
+        "ro_start": ([vp, i32, i32, C.c_uint64, P(i32), P(i32), P(i32)], C.c_int),
+        "ro_get_state": ([vp, i32, i32, P(i32), P(i32)], C.c_int),
+        "ro_set_connected": ([vp, i32, i32, i32], C.c_int), "ro_set_side": ([vp, i32, i32, i32], C.c_int),
+        "ro_crash": ([vp, i32, i32], C.c_int), "ro_restart": ([vp, i32, i32], C.c_int),
+        "ro_set_unreliable": ([vp, i32, i32, i32], C.c_int),
+        "ro_rpc_request_vote": ([vp, i32, i32, P(VoteArgs), P(VoteReply)], C.c_int),
+        "ro_rpc_append_entries": ([vp, i32, i32, P(AppendArgs), P(i32), P(C.c_uint64), P(AppendReply)], C.c_int),
+        "ro_read_state": ([vp, i32, vp, i64], C.c_int), "ro_write_state": ([vp, i32, vp, i64], C.c_int),
+        "ro_state_hash": ([vp, P(C.c_uint64), i64], C.c_int),
+        "ro_counters": ([vp, P(C.c_uint64)], C.c_int),
+        "ro_safety_check": ([vp], C.c_int), "ro_safety_flags": ([vp, P(C.c_uint32)], C.c_int),
+        "ro_snapshot_export": ([vp, i32, i32, vp, i64, P(i64)], C.c_int),
+        "ro_snapshot_import": ([vp, i32, i32, vp, i64], C.c_int),
+        "ro_leader_backoff": ([vp, i32, i32, i32, i32, i32], i32),
+        "ro_commit_rule": ([vp, i32, i32], i32),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = args, res
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class OracleEngine(EngineBase):
+    """Same Python surface as raft_amd.Engine, served by the CPU restatement."""
+
+    def __init__(self, cfg=None, lib_path=None, **kw):
+        self._lib = load(lib_path)
+        self.cfg = cfg if cfg is not None else _abi.make_config(**kw)
+        self.G, self.P, self.L = self.cfg.n_groups, self.cfg.n_peers, self.cfg.log_cap
+        self._h = self._lib.ro_create(C.byref(self.cfg))
+        if not self._h:
+            raise ValueError("ro_create rejected the config")
+        self._drained = {}
+
+    def _fn(self, name):
+        return getattr(self._lib, "ro_" + name)
+
+    def _rw(self, name, field, ptr, nbytes):
+        return self._fn(name)(self._h, field, ptr, nbytes)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ro_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self):
+        self._lib.ro_reset(self._h)
+        self._drained = {}
+
+    def sync(self):
+        pass
+
+    def now(self):
+        return self._lib.ro_now(self._h)
+
+    def set_full_persist(self, on):
+        self._lib.ro_set_full_persist(self._h, 1 if on else 0)
+
+    def step_mt(self, n_ticks, n_threads):
+        self._check(self._lib.ro_step_mt(self._h, n_ticks, n_threads), "step_mt")
+
+    def request_vote(self, g, p, term, candidate, last_log_index, last_log_term):
+        a, r = VoteArgs(term, candidate, last_log_index, last_log_term), VoteReply(0, 0)
+        self._check(self._lib.ro_rpc_request_vote(self._h, g, p, C.byref(a), C.byref(r)), "rpc_request_vote")
+        return r.term, bool(r.granted)
+
+    def request_vote_batch(self, groups, peers, args):
+        return [self.request_vote(g, p, *a) for g, p, a in zip(groups, peers, args)]
+
+    def append_entries(self, g, p, term, leader, prev_log_index, prev_log_term, entries, leader_commit):
+        n = len(entries)
+        a = AppendArgs(term, leader, prev_log_index, prev_log_term, leader_commit, n, 0)
+        r = AppendReply(0, 0, 0, 0)
+        ta = (C.c_int32 * max(1, n))(*[t for t, _ in entries])
+        ca = (C.c_uint64 * max(1, n))(*[c for _, c in entries])
+        self._check(self._lib.ro_rpc_append_entries(self._h, g, p, C.byref(a), ta, ca, C.byref(r)), "rpc_append_entries")
+        return r.term, bool(r.success), r.conflict_term, r.conflict_first_index
+
+    def append_entries_batch(self, groups, peers, reqs):
+        return [self.append_entries(g, p, *q) for g, p, q in zip(groups, peers, reqs)]
+
+    def start_batch(self, groups, peers, cmds):
+        return [self.start(int(g), int(p), int(c)) for g, p, c in zip(groups, peers, cmds)]
+
+    def leader_backoff(self, g, leader, follower, conflict_term, conflict_first_index):
+        return self._lib.ro_leader_backoff(self._h, g, leader, follower, conflict_term, conflict_first_index)
+
+    def commit_rule(self, g, leader):
+        return self._lib.ro_commit_rule(self._h, g, leader)
+
+    def drain_applied(self, g, p, cap=None):
+        """ApplyMsgs since the last drain, rebuilt from the cursor and the log."""
+        applied = int(self.read("applied")[g, p])
+        cmds = self.read("logcmd")[g, p]
+        last = self._drained.get((g, p), 0)
+        if applied < last:
+            last = 0
+        out = [(i, int(cmds[i])) for i in range(last + 1, applied + 1)]
+        self._drained[(g, p)] = applied
+        return out

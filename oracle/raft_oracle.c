@@ -1,0 +1,912 @@
+/*
+ * raft_oracle.c -- CPU restatement of the reference Raft peer (plain C).
+ * TEST INFRASTRUCTURE ONLY (see raft_oracle.h): it is the checker, never the
+ * product path.  Parity pin: the reference holds no golden vectors for this
+ * path; pinned by the reference tests' outcome properties and hand-derived
+ * known answers (tests/test_oracle_*.py).
+ *
+ * Each function follows the reference code it names, statement by statement.
+ * What replaces goroutines, wall clock and the labrpc channel network is the
+ * lockstep schedule below, which is one legal serialisation of the
+ * reference's mutex-guarded steps:
+ *
+ *   tick t (10 ms), per group:
+ *     1. control   : rolling-partition reshuffle, churn, client Start injection
+ *     2. actors    : for p = 0..P-1 (live peers): the election loop iteration
+ *                    if its 50/60 ms sleep is over, then the leader loop
+ *                    (monitor) if its 20 ms sleep is over.  An RPC is a direct
+ *                    call of the target's handler, gated by the network
+ *                    outcome (not delivered / handler ran, reply lost / round
+ *                    trip), exactly in the reference's sequential fan-out
+ *                    order with its break rules.  A round takes no time.
+ *     3. apply     : for p = 0..P-1: the apply loop iteration (10 ms period)
+ *     4. check     : one-leader-per-term among connected peers
+ *
+ * Fixed-capacity arrays stand in for Go slices: truncation only lowers the
+ * length and leaves the old words in place, as re-slicing a Go slice leaves
+ * its backing array.  States in which the reference would index past
+ * len(logs) raise RG_FLAG_REF_PANIC and read the stale words.
+ */
+#include "raft_oracle.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+  /* Raft struct, src/raft/raft.go:57-86 */
+  int32_t dead, term, vote, logLen, commit, applied;
+  int32_t next[RG_MAX_PEERS], match[RG_MAX_PEERS];
+  int32_t timer, state, hbTimer, stop, cnt;       /* timer, hbTimer in ticks */
+  /* locals of the election goroutine, raft.go:543-547 */
+  int32_t timeout, restart, elNext;
+  /* the monitor goroutine, raft.go:387-394 */
+  int32_t monAlive, first, monNext;
+  /* the Persister blob, persister.go:14-18, decoded */
+  int32_t snapHas, snapTerm, snapVote, snapLen, snapSync;
+  /* engine-side: harness connectivity and seeded streams */
+  int32_t connected, side;
+  uint32_t rngCtr, roundSeq;
+  uint64_t applyHash;
+  int32_t *logTerm;  uint64_t *logCmd;
+  int32_t *snapTerm_; uint64_t *snapCmd_;
+} peer_t;
+
+typedef struct {
+  peer_t peer[RG_MAX_PEERS];
+  uint64_t key;          /* per-group stream key */
+  int32_t startSeq, partNext, partEpoch, recMax;
+  uint32_t flags;
+  uint64_t *applyRec;    /* first command applied at each index, config.go:177-185 */
+} group_t;
+
+struct ro_engine {
+  rg_config cfg;
+  int P, L, G;
+  int64_t now;
+  int fullPersist;
+  group_t *groups;
+  uint64_t counters[RG_N_COUNTERS];
+};
+
+/* per-thread counter block so that ro_step_mt needs no atomics */
+typedef struct { uint64_t c[RG_N_COUNTERS]; } ctr_t;
+
+/* ---------------- seeded streams ---------------------------------------- */
+#define STREAM_ELECTION 1ull
+#define STREAM_NET      2ull
+#define STREAM_CMD      3ull
+#define STREAM_PART     4ull
+#define STREAM_CHURN    5ull
+
+static inline uint64_t sm64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+static inline uint64_t group_key(uint64_t seed, int64_t ggid) { return sm64(sm64(seed) ^ (uint64_t)ggid); }
+static inline uint64_t stream_hash(uint64_t key, uint64_t stream, uint32_t a, uint32_t b) {
+  return sm64(key ^ (stream << 56) ^ ((uint64_t)a << 32) ^ (uint64_t)b);
+}
+
+/* nextRandom(), raft.go:532-534 */
+static int32_t next_random(group_t *g, int p) {
+  peer_t *rf = &g->peer[p];
+  uint64_t h = stream_hash(g->key, STREAM_ELECTION, (uint32_t)p, rf->rngCtr++);
+  return (int32_t)(h % RG_TIMEOUT_SPAN_MS) + RG_TIMEOUT_BASE_MS;
+}
+
+/* ---------------- persist / readPersist --------------------------------- */
+/* persist(), raft.go:107-123: currentTerm, voteFor, logs[0:commitIndex+1]. */
+static void persist(ro_engine *e, ctr_t *c, peer_t *rf) {
+  int n = rf->commit + 1;
+  if (n > e->L) n = e->L;
+  rf->snapTerm = rf->term;
+  rf->snapVote = rf->vote;
+  int from = e->fullPersist ? 0 : rf->snapSync;
+  for (int i = from; i < n; i++) { rf->snapTerm_[i] = rf->logTerm[i]; rf->snapCmd_[i] = rf->logCmd[i]; }
+  if (n > rf->snapSync) { c->c[RG_C_PERSIST_ENTRIES] += (uint64_t)(n - rf->snapSync); rf->snapSync = n; }
+  rf->snapLen = n;
+  rf->snapHas = 1;
+  c->c[RG_C_PERSISTS]++;
+}
+
+/* Make(), raft.go:700-731, with readPersist(), raft.go:129-152, and the
+ * start of election(), raft.go:538-547. */
+static void make_peer(ro_engine *e, ctr_t *c, group_t *g, int p, int32_t now) {
+  peer_t *rf = &g->peer[p];
+  rf->dead = 0;
+  rf->term = 0;
+  rf->vote = -1;
+  rf->logTerm[0] = 0; rf->logCmd[0] = 0;   /* Entry{Command:"init", Term:0} */
+  rf->logLen = 1;
+  rf->commit = 0;
+  rf->applied = 0;
+  rf->timer = now;
+  rf->state = RG_FOLLOWER;
+  rf->stop = 0;
+  rf->cnt = 0;
+  rf->hbTimer = now;
+  if (rf->snapHas && rf->snapLen >= 1) {            /* readPersist */
+    rf->term = rf->snapTerm;
+    rf->vote = rf->snapVote;
+    int n = rf->snapLen;
+    int from = e->fullPersist ? 0 : rf->snapSync;
+    for (int i = from; i < n; i++) { rf->logTerm[i] = rf->snapTerm_[i]; rf->logCmd[i] = rf->snapCmd_[i]; }
+    if (n > rf->snapSync) rf->snapSync = n;
+    rf->logLen = n;
+    persist(e, c, rf);                              /* :147, commitIndex is still 0 */
+    rf->commit = rf->logLen - 1;                    /* :148 */
+  }
+  rf->monAlive = 0; rf->first = 0; rf->monNext = 0;
+  rf->restart = 0;
+  rf->timeout = 0;
+  if (!(rf->term == 0 && p == 0)) rf->timeout = next_random(g, p);   /* :545-547 */
+  rf->elNext = now;                                 /* first loop iteration right away */
+}
+
+/* GetState(), raft.go:90-100 */
+static int is_leader(const peer_t *rf) { return !rf->dead && !rf->stop && rf->state == RG_LEADER; }
+
+/* ---------------- RPC handlers ------------------------------------------ */
+/* RequestVote(), raft.go:200-232 */
+static void request_vote(ro_engine *e, ctr_t *c, peer_t *rf, int32_t now, const rg_vote_args *a, rg_vote_reply *r) {
+  if (rf->dead) return;
+  if (a->term < rf->term) {
+    r->granted = 0;
+    r->term = rf->term;
+  } else {
+    if (a->term > rf->term) { rf->term = a->term; rf->vote = -1; persist(e, c, rf); }
+    r->term = rf->term;
+    rf->state = RG_FOLLOWER;                                      /* :216 */
+    int32_t myLastTerm = rf->logTerm[rf->commit];                 /* logs[commitIndex].Term */
+    if ((rf->vote == -1 || rf->vote == a->candidate) &&
+        (a->last_log_term > myLastTerm || (a->last_log_term == myLastTerm && a->last_log_index >= rf->commit))) {
+      r->granted = 1;
+      rf->vote = a->candidate;
+      persist(e, c, rf);
+      rf->timer = now;
+    } else {
+      r->granted = 0;
+    }
+  }
+}
+
+/* AppendEntries(), raft.go:270-321.  Entries are (terms, cmds)[0..n). */
+static void append_entries(ro_engine *e, ctr_t *c, group_t *g, peer_t *rf, int32_t now, const rg_append_args *a,
+                           const int32_t *et, const uint64_t *ec, rg_append_reply *r) {
+  if (rf->dead) return;
+  if (a->term < rf->term) {
+    r->success = 0;
+    r->term = rf->term;
+  } else {
+    rf->state = RG_FOLLOWER;
+    rf->vote = a->leader;                                         /* :281 */
+    if (rf->term < a->term) { rf->term = a->term; persist(e, c, rf); }
+    r->term = rf->term;
+    rf->timer = now;
+    if (a->prev_log_index + 1 <= rf->logLen && rf->logTerm[a->prev_log_index] == a->prev_log_term) {
+      r->success = 1;
+      int base = a->prev_log_index + 1;                           /* logs[0:Prev+1] ++ Entries */
+      for (int i = 0; i < a->n_entries; i++) { rf->logTerm[base + i] = et[i]; rf->logCmd[base + i] = ec[i]; }
+      if (a->n_entries > 0 && base < rf->snapSync) rf->snapSync = base;
+      rf->logLen = base + a->n_entries;
+      if (a->leader_commit > rf->commit) {
+        if (rf->logLen - 1 < a->leader_commit) rf->commit = rf->logLen - 1;
+        else rf->commit = a->leader_commit;
+      }
+      if (rf->commit > rf->logLen - 1) g->flags |= RG_FLAG_REF_PANIC;
+      persist(e, c, rf);
+      c->c[RG_C_ENTRIES_REPLICATED] += (uint64_t)a->n_entries;
+    } else {
+      r->success = 0;
+      if (a->prev_log_index + 1 > rf->logLen) {
+        r->conflict_term = -1;
+        r->conflict_first_index = rf->logLen;
+      } else {
+        r->conflict_term = rf->logTerm[a->prev_log_index];
+        int index = a->prev_log_index;
+        while (index >= 0 && rf->logTerm[index] == r->conflict_term) index--;
+        r->conflict_first_index = index + 1;
+      }
+      c->c[RG_C_AE_CONFLICTS]++;
+    }
+  }
+}
+
+/* ---------------- network (labrpc.go:216-307) --------------------------- */
+enum { NET_LOST = 0, NET_REPLY_LOST = 1, NET_OK = 2 };
+
+static int net_outcome(const ro_engine *e, const group_t *g, int s, int j, uint32_t seq) {
+  const peer_t *a = &g->peer[s], *b = &g->peer[j];
+  if (!(a->connected && b->connected && a->side == b->side) || b->dead) return NET_LOST;
+  const rg_config *cf = &e->cfg;
+  if (cf->req_drop_permille == 0 && cf->reply_drop_permille == 0 && cf->reply_delay_permille == 0) return NET_OK;
+  uint64_t h = stream_hash(g->key, STREAM_NET, ((uint32_t)s << 8) | (uint32_t)j, seq);
+  if ((int32_t)((h & 0xFFFFF) % 1000) < cf->req_drop_permille) return NET_LOST;              /* :226 */
+  if ((int32_t)(((h >> 20) & 0xFFFFF) % 1000) < cf->reply_drop_permille) return NET_REPLY_LOST;   /* :273 */
+  if ((int32_t)(((h >> 40) & 0xFFFFF) % 1000) < cf->reply_delay_permille) return NET_REPLY_LOST;  /* :276 */
+  return NET_OK;
+}
+
+/* ---------------- Start (raft.go:344-364) ------------------------------- */
+static void start_cmd(ro_engine *e, ctr_t *c, group_t *g, int p, uint64_t cmd, int32_t *index, int32_t *term, int32_t *leader) {
+  peer_t *rf = &g->peer[p];
+  *index = -1;
+  *term = rf->term;
+  *leader = is_leader(rf);
+  if (*leader) {
+    if (rf->logLen >= e->L) { g->flags |= RG_FLAG_LOG_OVERFLOW; *leader = 0; return; }
+    *index = rf->logLen;
+    rf->logTerm[rf->logLen] = rf->term;
+    rf->logCmd[rf->logLen] = cmd;
+    if (rf->logLen < rf->snapSync) rf->snapSync = rf->logLen;
+    rf->logLen++;
+    persist(e, c, rf);
+    c->c[RG_C_ENTRIES_STARTED]++;
+  }
+}
+
+/* ---------------- election loop iteration (raft.go:548-668) ------------- */
+static void election_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t now) {
+  peer_t *rf = &g->peer[me];
+  const int l = e->P;
+  int32_t state = rf->state;
+  int32_t timer = rf->timer;
+  switch (state) {
+  case RG_FOLLOWER:
+    if ((now - timer) * RG_TICK_MS > rf->timeout) {                /* :557 */
+      rf->state = RG_CANDIDATE;
+      rf->timeout = next_random(g, me);
+      c->c[RG_C_TIMEOUTS]++;
+    }
+    break;
+  case RG_CANDIDATE: {
+    rf->timeout = RG_CANDIDATE_WINDOW_MS;
+    rf->timer = now;
+    if (!rf->restart) rf->term = rf->term + 1; else rf->restart = 0;
+    rf->vote = me;
+    persist(e, c, rf);
+    rg_vote_args args = { rf->term, me, rf->commit, rf->logTerm[rf->commit] };   /* :579-584 */
+    rg_vote_reply reply = { rf->term, 0 };
+    persist(e, c, rf);
+    c->c[RG_C_RV_ROUNDS]++;
+    uint32_t seq = rf->roundSeq++;
+    int voteCnt = 1;
+    for (int i = 0; i < l && state == RG_CANDIDATE; i++) {
+      state = rf->state;
+      if (i != me) {
+        int out = net_outcome(e, g, me, i, seq);
+        c->c[RG_C_RPC_SENT]++;
+        int ok = 0;
+        if (out != NET_LOST) {
+          rg_vote_reply wire = { 0, 0 };
+          request_vote(e, c, &g->peer[i], now, &args, &wire);
+          c->c[RG_C_RPC_DELIVERED]++;
+          if (out == NET_OK) {           /* gob leaves zero fields of the shared reply alone, labgob.go:116-121 */
+            ok = 1;
+            if (wire.term != 0) reply.term = wire.term;
+            if (wire.granted) reply.granted = 1;
+            c->c[RG_C_RPC_REPLIED]++;
+          }
+        }
+        if (ok) {
+          if (reply.granted) { voteCnt++; reply.granted = 0; }
+          if (rf->term != args.term) break;
+          if (reply.term > rf->term) {                             /* :622-627 */
+            rf->state = RG_FOLLOWER;
+            rf->vote = -1;
+            persist(e, c, rf);
+            c->c[RG_C_STEPDOWNS]++;
+            break;
+          }
+        }
+      }
+    }
+    state = rf->state;
+    if (!rf->dead) {
+      if (state == RG_FOLLOWER) {
+        rf->timeout = next_random(g, me);                          /* :639 */
+      } else if (state == RG_CANDIDATE) {
+        if ((now - rf->timer) * RG_TICK_MS < rf->timeout && 2 * voteCnt > l) {   /* :641 */
+          rf->stop = 0;
+          rf->cnt = 0;
+          rf->state = RG_LEADER;
+          rf->hbTimer = now;
+          for (int i = 0; i < l; i++) rf->next[i] = rf->logLen;
+          for (int i = 0; i < l; i++) rf->match[i] = 0;
+          rf->monAlive = 1; rf->first = 1; rf->monNext = now;      /* go monitor(rf) */
+          c->c[RG_C_ELECTIONS_WON]++;
+        } else {
+          rf->restart = 1;
+        }
+      }
+    }
+    state = RG_CANDIDATE;   /* the switch ran on the value loaded at the top */
+    break;
+  }
+  default: break;
+  }
+  rf->elNext = now + RG_ELECTION_PERIOD + (state == RG_LEADER ? RG_ELECTION_LEADER_EXTRA : 0);
+}
+
+/* commit rule, raft.go:400-416.  Returns 1 when commitIndex advanced. */
+static int commit_rule(ro_engine *e, ctr_t *c, peer_t *rf, int me) {
+  const int l = e->P;
+  int N = rf->logLen - 1;
+  for (; rf->state == RG_LEADER && N > rf->commit && rf->logTerm[N] == rf->term; N--) {
+    int cnt = 1;
+    for (int i = 0; i < l; i++) if (i != me && rf->match[i] >= N) cnt++;
+    if (2 * cnt > l && rf->logTerm[N] == rf->term) {
+      c->c[RG_C_ENTRIES_COMMITTED] += (uint64_t)(N - rf->commit);
+      rf->commit = N;
+      persist(e, c, rf);
+      return 1;
+    }
+  }
+  return 0;
+}
+
+/* leader's handling of a failed AppendEntries reply, raft.go:493-505 */
+static int32_t leader_backoff(const peer_t *rf, int i, int32_t conflictTerm, int32_t conflictFirst) {
+  if (conflictTerm >= 0) {
+    int index = rf->next[i] - 1;
+    while (rf->logTerm[index] > conflictTerm) index--;
+    if (rf->logTerm[index] == conflictTerm) return index + 1;
+    return conflictFirst;
+  }
+  return conflictFirst;
+}
+
+/* leader loop, raft.go:395-529, run until it would sleep or exit */
+static void monitor_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t now) {
+  peer_t *rf = &g->peer[me];
+  const int l = e->P;
+  for (;;) {
+    if (rf->dead) { rf->monAlive = 0; rf->monNext = 0; return; }
+    int isleader = is_leader(rf);
+    int active = 1;
+    if (!isleader) { rf->monAlive = 0; rf->monNext = 0; return; }   /* :526-528 */
+    if (commit_rule(e, c, rf, me)) rf->first = 1;
+    int32_t timer = rf->hbTimer;
+    int32_t logLen = rf->logLen;
+    int32_t commitIndex = rf->commit;
+    int32_t since = (now - timer) * RG_TICK_MS;
+    if (rf->first || since >= RG_HB_IDLE_MS || (commitIndex < logLen - 1 && since >= RG_HB_BACKLOG_MS)) {   /* :421 */
+      rf->first = 0;
+      c->c[RG_C_AE_ROUNDS]++;
+      uint32_t seq = rf->roundSeq++;
+      for (int i = 0; i < l; i++) {
+        if (!is_leader(rf)) break;                                  /* :424-427 */
+        if (i == me) continue;
+        rg_append_args args;
+        if (rf->next[i] <= logLen) {
+          args.term = rf->term;
+          args.leader = me;
+          args.prev_log_index = rf->next[i] - 1;
+          args.prev_log_term = rf->logTerm[rf->next[i] - 1];
+          args.n_entries = logLen - rf->next[i];
+          args.entry_off = rf->next[i];
+          args.leader_commit = rf->commit;
+        } else {
+          break;                                                    /* :451-454 */
+        }
+        rg_append_reply reply = { 0, 0, 0, 0 };
+        int out = net_outcome(e, g, me, i, seq);
+        c->c[RG_C_RPC_SENT]++;
+        int ok = 0;
+        if (out != NET_LOST) {
+          append_entries(e, c, g, &g->peer[i], now, &args, rf->logTerm + args.entry_off, rf->logCmd + args.entry_off, &reply);
+          c->c[RG_C_RPC_DELIVERED]++;
+          if (out == NET_OK) { ok = 1; c->c[RG_C_RPC_REPLIED]++; }
+        }
+        if (ok) {
+          active++;
+          if (rf->term != args.term) break;
+          else if (reply.term > rf->term) {                         /* :482-487 */
+            rf->state = RG_FOLLOWER;
+            rf->term = reply.term;
+            persist(e, c, rf);
+            c->c[RG_C_STEPDOWNS]++;
+            break;
+          } else {
+            if (reply.success) {
+              rf->next[i] = logLen;
+              rf->match[i] = rf->next[i] - 1;
+            } else {
+              rf->next[i] = leader_backoff(rf, i, reply.conflict_term, reply.conflict_first_index);
+            }
+          }
+        }
+      }
+      if (active == 1 && rf->cnt <= 3) {                            /* :514-520 */
+        rf->cnt++;
+        if (rf->cnt > 3) rf->stop = 1;
+      }
+      rf->hbTimer = now;
+    } else {
+      rf->monNext = now + RG_MONITOR_POLL;                          /* :524 */
+      return;
+    }
+  }
+}
+
+/* apply loop iteration, raft.go:676-686, and the harness reader, config.go:170-194 */
+static void apply_step(ro_engine *e, ctr_t *c, group_t *g, int p) {
+  peer_t *rf = &g->peer[p];
+  while (rf->commit > rf->applied) {
+    rf->applied++;
+    int idx = rf->applied;
+    if (idx >= rf->logLen) g->flags |= RG_FLAG_REF_PANIC;
+    if (idx >= e->L) idx = e->L - 1;
+    uint64_t cmd = rf->logCmd[idx];
+    rf->applyHash = sm64(rf->applyHash ^ cmd ^ ((uint64_t)(uint32_t)rf->applied << 40));
+    if (rf->applied <= g->recMax) {
+      if (g->applyRec[idx] != cmd) g->flags |= RG_FLAG_STATE_MACHINE;
+    } else {
+      if (rf->applied != g->recMax + 1) g->flags |= RG_FLAG_APPLY_ORDER;
+      g->applyRec[idx] = cmd;
+      g->recMax = rf->applied;
+    }
+    c->c[RG_C_ENTRIES_APPLIED]++;
+  }
+}
+
+/* ---------------- harness verbs (config.go:99-278) ----------------------- */
+static void crash1(group_t *g, int p) {
+  g->peer[p].connected = 0;
+  g->peer[p].dead = 1;
+}
+static void start1(ro_engine *e, ctr_t *c, group_t *g, int p, int32_t now) {
+  crash1(g, p);
+  make_peer(e, c, g, p, now);
+}
+
+/* ---------------- control phase ----------------------------------------- */
+static void control_step(ro_engine *e, ctr_t *c, group_t *g, int32_t now) {
+  const rg_config *cf = &e->cfg;
+  const int P = e->P;
+  /* rolling partitions, kvraft/test_test.go:124-143 + kvraft/config.go:174-186 */
+  if (cf->part_period > 0 && now == g->partNext) {
+    uint32_t ep = (uint32_t)g->partEpoch;
+    for (int p = 0; p < P; p++) g->peer[p].side = (int32_t)(stream_hash(g->key, STREAM_PART, ep, (uint32_t)p + 1) & 1);
+    uint64_t h = stream_hash(g->key, STREAM_PART, ep, 0);
+    g->partNext = now + cf->part_period + (cf->part_jitter > 0 ? (int32_t)(h % (uint64_t)cf->part_jitter) : 0);
+    g->partEpoch++;
+  }
+  /* churn, test_test.go:893-919 */
+  if (cf->churn_period > 0 && now > 0 && now % cf->churn_period == 0) {
+    uint32_t it = (uint32_t)(now / cf->churn_period);
+    uint64_t h1 = stream_hash(g->key, STREAM_CHURN, it, 0);
+    uint64_t h2 = stream_hash(g->key, STREAM_CHURN, it, 1);
+    uint64_t h3 = stream_hash(g->key, STREAM_CHURN, it, 2);
+    if ((int32_t)((h1 & 0xFFFFF) % 1000) < cf->churn_disconnect_permille) {
+      int i = (int)((h1 >> 32) % (uint64_t)P);
+      g->peer[i].connected = 0;
+    }
+    if ((int32_t)((h2 & 0xFFFFF) % 1000) < cf->churn_restart_permille) {
+      int i = (int)((h2 >> 32) % (uint64_t)P);
+      if (g->peer[i].dead) start1(e, c, g, i, now);
+      g->peer[i].connected = 1;
+    }
+    if ((int32_t)((h3 & 0xFFFFF) % 1000) < cf->churn_crash_permille) {
+      int i = (int)((h3 >> 32) % (uint64_t)P);
+      if (!g->peer[i].dead) crash1(g, i);
+    }
+  }
+  /* client Starts, config.go:436-451 / test_test.go:697-703 */
+  if (cf->start_period > 0 && now >= cf->start_first_tick &&
+      (now - cf->start_first_tick) % cf->start_period == 0) {
+    for (int p = 0; p < P; p++) {
+      if (g->startSeq >= cf->start_max) break;
+      peer_t *rf = &g->peer[p];
+      if (rf->dead) continue;
+      if (cf->start_mode == RG_START_ONE && !rf->connected) continue;
+      if (!is_leader(rf)) continue;
+      uint64_t cmd = stream_hash(g->key, STREAM_CMD, 0, (uint32_t)g->startSeq);
+      int32_t idx, term, ok;
+      start_cmd(e, c, g, p, cmd, &idx, &term, &ok);
+      if (ok) {
+        g->startSeq++;
+        if (cf->start_mode == RG_START_ONE) break;
+      }
+    }
+  }
+}
+
+/* checkOneLeader's invariant, config.go:307-320 */
+static void check_leaders(ro_engine *e, group_t *g) {
+  for (int a = 0; a < e->P; a++) {
+    const peer_t *x = &g->peer[a];
+    if (!x->connected || !is_leader(x)) continue;
+    for (int b = a + 1; b < e->P; b++) {
+      const peer_t *y = &g->peer[b];
+      if (y->connected && is_leader(y) && y->term == x->term) g->flags |= RG_FLAG_ELECTION_SAFETY;
+    }
+  }
+}
+
+static void tick_group(ro_engine *e, ctr_t *c, group_t *g, int32_t now) {
+  control_step(e, c, g, now);
+  for (int p = 0; p < e->P; p++) {
+    peer_t *rf = &g->peer[p];
+    if (rf->dead) continue;
+    if (rf->elNext <= now) election_step(e, c, g, p, now);
+    if (!rf->dead && rf->monAlive && rf->monNext <= now) monitor_step(e, c, g, p, now);
+  }
+  for (int p = 0; p < e->P; p++) if (!g->peer[p].dead) apply_step(e, c, g, p);
+  check_leaders(e, g);
+}
+
+/* ---------------- engine lifecycle -------------------------------------- */
+static void init_group(ro_engine *e, group_t *g, int64_t ggid) {
+  ctr_t scratch; memset(&scratch, 0, sizeof scratch);
+  g->key = group_key(e->cfg.seed, ggid);
+  g->startSeq = 0; g->partEpoch = 0; g->recMax = 0; g->flags = 0;
+  g->partNext = e->cfg.part_period > 0 ? e->cfg.part_period : 0;
+  memset(g->applyRec, 0, sizeof(uint64_t) * (size_t)e->L);
+  for (int p = 0; p < e->P; p++) {
+    peer_t *rf = &g->peer[p];
+    int32_t *lt = rf->logTerm, *st = rf->snapTerm_; uint64_t *lc = rf->logCmd, *sc = rf->snapCmd_;
+    memset(rf, 0, sizeof *rf);
+    rf->logTerm = lt; rf->snapTerm_ = st; rf->logCmd = lc; rf->snapCmd_ = sc;
+    memset(lt, 0, sizeof(int32_t) * (size_t)e->L); memset(st, 0, sizeof(int32_t) * (size_t)e->L);
+    memset(lc, 0, sizeof(uint64_t) * (size_t)e->L); memset(sc, 0, sizeof(uint64_t) * (size_t)e->L);
+    rf->connected = 1; rf->side = 0;
+    rf->snapSync = 1;          /* entry 0 is the same sentinel in every array */
+    make_peer(e, &scratch, g, p, 0);
+  }
+}
+
+static int valid_config(const rg_config *c) {
+  if (!c) return 0;
+  if (c->n_groups < 1 || c->n_peers < 2 || c->n_peers > RG_MAX_PEERS || c->log_cap < 2) return 0;
+  if (c->start_period < 0 || c->part_period < 0 || c->churn_period < 0) return 0;
+  if (c->start_period > 0 && (c->start_max < 0 || c->start_max + 1 > c->log_cap)) return 0;
+  return 1;
+}
+
+ro_engine *ro_create(const rg_config *cfg) {
+  if (!valid_config(cfg)) return NULL;
+  ro_engine *e = (ro_engine *)calloc(1, sizeof *e);
+  if (!e) return NULL;
+  e->cfg = *cfg; e->P = cfg->n_peers; e->L = cfg->log_cap; e->G = cfg->n_groups;
+  e->groups = (group_t *)calloc((size_t)e->G, sizeof(group_t));
+  if (!e->groups) { free(e); return NULL; }
+  for (int g = 0; g < e->G; g++) {
+    group_t *gr = &e->groups[g];
+    gr->applyRec = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)e->L);
+    for (int p = 0; p < e->P; p++) {
+      peer_t *rf = &gr->peer[p];
+      rf->logTerm = (int32_t *)malloc(sizeof(int32_t) * (size_t)e->L);
+      rf->snapTerm_ = (int32_t *)malloc(sizeof(int32_t) * (size_t)e->L);
+      rf->logCmd = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)e->L);
+      rf->snapCmd_ = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)e->L);
+    }
+  }
+  ro_reset(e);
+  return e;
+}
+
+void ro_reset(ro_engine *e) {
+  e->now = 0;
+  memset(e->counters, 0, sizeof e->counters);
+  for (int g = 0; g < e->G; g++) init_group(e, &e->groups[g], e->cfg.group_base + g);
+}
+
+void ro_destroy(ro_engine *e) {
+  if (!e) return;
+  for (int g = 0; g < e->G; g++) {
+    group_t *gr = &e->groups[g];
+    free(gr->applyRec);
+    for (int p = 0; p < e->P; p++) {
+      free(gr->peer[p].logTerm); free(gr->peer[p].snapTerm_); free(gr->peer[p].logCmd); free(gr->peer[p].snapCmd_);
+    }
+  }
+  free(e->groups);
+  free(e);
+}
+
+void ro_set_full_persist(ro_engine *e, int on) { e->fullPersist = on; }
+int64_t ro_now(ro_engine *e) { return e->now; }
+
+static void add_counters(ro_engine *e, const ctr_t *c) { for (int i = 0; i < RG_N_COUNTERS; i++) e->counters[i] += c->c[i]; }
+
+int ro_step(ro_engine *e, int32_t n_ticks) {
+  if (!e || n_ticks < 0) return RG_ERR_ARG;
+  ctr_t c; memset(&c, 0, sizeof c);
+  /* groups are independent: advance each one through all ticks in turn */
+  for (int g = 0; g < e->G; g++)
+    for (int32_t t = 0; t < n_ticks; t++) tick_group(e, &c, &e->groups[g], (int32_t)(e->now + t));
+  c.c[RG_C_GROUP_TICKS] += (uint64_t)e->G * (uint64_t)n_ticks;
+  add_counters(e, &c);
+  e->now += n_ticks;
+  return RG_OK;
+}
+
+typedef struct { ro_engine *e; int g0, g1; int32_t n; ctr_t c; } job_t;
+static void *mt_worker(void *arg) {
+  job_t *j = (job_t *)arg;
+  for (int g = j->g0; g < j->g1; g++)
+    for (int32_t t = 0; t < j->n; t++) tick_group(j->e, &j->c, &j->e->groups[g], (int32_t)(j->e->now + t));
+  return NULL;
+}
+
+int ro_step_mt(ro_engine *e, int32_t n_ticks, int32_t n_threads) {
+  if (!e || n_ticks < 0 || n_threads < 1) return RG_ERR_ARG;
+  if (n_threads > e->G) n_threads = e->G;
+  if (n_threads > 256) n_threads = 256;
+  job_t *jobs = (job_t *)calloc((size_t)n_threads, sizeof(job_t));
+  pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+  if (!jobs || !th) { free(jobs); free(th); return RG_ERR_NOMEM; }
+  for (int i = 0; i < n_threads; i++) {
+    jobs[i].e = e; jobs[i].n = n_ticks;
+    jobs[i].g0 = (int)((int64_t)e->G * i / n_threads);
+    jobs[i].g1 = (int)((int64_t)e->G * (i + 1) / n_threads);
+    pthread_create(&th[i], NULL, mt_worker, &jobs[i]);
+  }
+  for (int i = 0; i < n_threads; i++) { pthread_join(th[i], NULL); add_counters(e, &jobs[i].c); }
+  e->counters[RG_C_GROUP_TICKS] += (uint64_t)e->G * (uint64_t)n_ticks;
+  e->now += n_ticks;
+  free(jobs); free(th);
+  return RG_OK;
+}
+
+/* ---------------- verbs -------------------------------------------------- */
+#define CHECK_GP(e, g, p) do { if (!(e)) return RG_ERR_ARG; if ((g) < 0 || (g) >= (e)->G || (p) < 0 || (p) >= (e)->P) return RG_ERR_RANGE; } while (0)
+
+int ro_start(ro_engine *e, int32_t g, int32_t p, uint64_t cmd, int32_t *index, int32_t *term, int32_t *leader) {
+  CHECK_GP(e, g, p);
+  ctr_t c; memset(&c, 0, sizeof c);
+  int32_t i, t, l;
+  start_cmd(e, &c, &e->groups[g], p, cmd, &i, &t, &l);
+  add_counters(e, &c);
+  if (index) *index = i;
+  if (term) *term = t;
+  if (leader) *leader = l;
+  return RG_OK;
+}
+int ro_get_state(ro_engine *e, int32_t g, int32_t p, int32_t *term, int32_t *leader) {
+  CHECK_GP(e, g, p);
+  const peer_t *rf = &e->groups[g].peer[p];
+  if (term) *term = rf->term;
+  if (leader) *leader = is_leader(rf);
+  return RG_OK;
+}
+int ro_set_connected(ro_engine *e, int32_t g, int32_t p, int32_t on) { CHECK_GP(e, g, p); e->groups[g].peer[p].connected = on ? 1 : 0; return RG_OK; }
+int ro_set_side(ro_engine *e, int32_t g, int32_t p, int32_t side) { CHECK_GP(e, g, p); e->groups[g].peer[p].side = side & 1; return RG_OK; }
+int ro_crash(ro_engine *e, int32_t g, int32_t p) { CHECK_GP(e, g, p); crash1(&e->groups[g], p); return RG_OK; }
+int ro_restart(ro_engine *e, int32_t g, int32_t p) {
+  CHECK_GP(e, g, p);
+  ctr_t c; memset(&c, 0, sizeof c);
+  start1(e, &c, &e->groups[g], p, (int32_t)e->now);
+  add_counters(e, &c);
+  return RG_OK;
+}
+int ro_set_unreliable(ro_engine *e, int32_t a, int32_t b, int32_t d) {
+  if (!e || a < 0 || b < 0 || d < 0 || a > 1000 || b > 1000 || d > 1000) return RG_ERR_ARG;
+  e->cfg.req_drop_permille = a; e->cfg.reply_drop_permille = b; e->cfg.reply_delay_permille = d;
+  return RG_OK;
+}
+
+int ro_rpc_request_vote(ro_engine *e, int32_t g, int32_t p, const rg_vote_args *a, rg_vote_reply *r) {
+  CHECK_GP(e, g, p);
+  if (!a || !r) return RG_ERR_ARG;
+  ctr_t c; memset(&c, 0, sizeof c);
+  request_vote(e, &c, &e->groups[g].peer[p], (int32_t)e->now, a, r);
+  add_counters(e, &c);
+  return RG_OK;
+}
+int ro_rpc_append_entries(ro_engine *e, int32_t g, int32_t p, const rg_append_args *a,
+                          const int32_t *et, const uint64_t *ec, rg_append_reply *r) {
+  CHECK_GP(e, g, p);
+  if (!a || !r) return RG_ERR_ARG;
+  if (a->prev_log_index < 0 || a->n_entries < 0 || (int64_t)a->prev_log_index + 1 + a->n_entries > e->L) return RG_ERR_RANGE;
+  if (a->n_entries > 0 && (!et || !ec)) return RG_ERR_ARG;
+  ctr_t c; memset(&c, 0, sizeof c);
+  append_entries(e, &c, &e->groups[g], &e->groups[g].peer[p], (int32_t)e->now, a,
+                 et ? et + a->entry_off : NULL, ec ? ec + a->entry_off : NULL, r);
+  add_counters(e, &c);
+  return RG_OK;
+}
+
+int32_t ro_leader_backoff(ro_engine *e, int32_t g, int32_t leader, int32_t follower, int32_t ct, int32_t cf) {
+  return leader_backoff(&e->groups[g].peer[leader], follower, ct, cf);
+}
+int32_t ro_commit_rule(ro_engine *e, int32_t g, int32_t leader) {
+  ctr_t c; memset(&c, 0, sizeof c);
+  int r = commit_rule(e, &c, &e->groups[g].peer[leader], leader);
+  add_counters(e, &c);
+  return r;
+}
+
+/* ---------------- bulk state access -------------------------------------- */
+static int32_t *peer_i32(peer_t *rf, int field) {
+  switch (field) {
+  case RG_F_TERM: return &rf->term;       case RG_F_VOTE: return &rf->vote;       case RG_F_STATE: return &rf->state;
+  case RG_F_COMMIT: return &rf->commit;   case RG_F_APPLIED: return &rf->applied; case RG_F_LOGLEN: return &rf->logLen;
+  case RG_F_TIMER: return &rf->timer;     case RG_F_TIMEOUT: return &rf->timeout; case RG_F_HBTIMER: return &rf->hbTimer;
+  case RG_F_STOP: return &rf->stop;       case RG_F_CNT: return &rf->cnt;         case RG_F_DEAD: return &rf->dead;
+  case RG_F_RESTART: return &rf->restart; case RG_F_FIRST: return &rf->first;     case RG_F_MONALIVE: return &rf->monAlive;
+  case RG_F_ELNEXT: return &rf->elNext;   case RG_F_MONNEXT: return &rf->monNext;
+  case RG_F_RNGCTR: return (int32_t *)&rf->rngCtr; case RG_F_ROUNDSEQ: return (int32_t *)&rf->roundSeq;
+  case RG_F_SNAPHAS: return &rf->snapHas; case RG_F_SNAPTERM: return &rf->snapTerm; case RG_F_SNAPVOTE: return &rf->snapVote;
+  case RG_F_SNAPLEN: return &rf->snapLen; case RG_F_CONNECTED: return &rf->connected; case RG_F_SIDE: return &rf->side;
+  default: return NULL;
+  }
+}
+static int32_t *group_i32(group_t *g, int field) {
+  switch (field) {
+  case RG_F_STARTSEQ: return &g->startSeq; case RG_F_PARTNEXT: return &g->partNext; case RG_F_PARTEPOCH: return &g->partEpoch;
+  case RG_F_RECMAX: return &g->recMax;     case RG_F_GFLAGS: return (int32_t *)&g->flags;
+  default: return NULL;
+  }
+}
+
+static int64_t field_bytes(const ro_engine *e, int field) {
+  int64_t G = e->G, P = e->P, L = e->L;
+  if (field >= 0 && field < RG_F_PEER_I32_END) return G * P * 4;
+  switch (field) {
+  case RG_F_APPLYHASH: return G * P * 8;
+  case RG_F_NEXTINDEX: case RG_F_MATCHINDEX: return G * P * P * 4;
+  case RG_F_LOGTERM: case RG_F_SNAPLOGTERM: return G * P * L * 4;
+  case RG_F_LOGCMD: case RG_F_SNAPLOGCMD: return G * P * L * 8;
+  case RG_F_STARTSEQ: case RG_F_PARTNEXT: case RG_F_PARTEPOCH: case RG_F_RECMAX: case RG_F_GFLAGS: return G * 4;
+  case RG_F_APPLYREC: return G * L * 8;
+  default: return -1;
+  }
+}
+
+static int rw_state(ro_engine *e, int32_t field, void *buf, int64_t bytes, int wr) {
+  if (!e || !buf) return RG_ERR_ARG;
+  int64_t need = field_bytes(e, field);
+  if (need < 0 || bytes != need) return RG_ERR_ARG;
+  const int G = e->G, P = e->P, L = e->L;
+  for (int g = 0; g < G; g++) {
+    group_t *gr = &e->groups[g];
+    if (field >= RG_F_STARTSEQ && field <= RG_F_GFLAGS) {
+      int32_t *w = group_i32(gr, field), *b = (int32_t *)buf + g;
+      if (wr) *w = *b; else *b = *w;
+      continue;
+    }
+    if (field == RG_F_APPLYREC) {
+      uint64_t *b = (uint64_t *)buf + (int64_t)g * L;
+      if (wr) memcpy(gr->applyRec, b, sizeof(uint64_t) * (size_t)L); else memcpy(b, gr->applyRec, sizeof(uint64_t) * (size_t)L);
+      continue;
+    }
+    for (int p = 0; p < P; p++) {
+      peer_t *rf = &gr->peer[p];
+      int64_t gp = (int64_t)g * P + p;
+      if (field < RG_F_PEER_I32_END) {
+        int32_t *w = peer_i32(rf, field), *b = (int32_t *)buf + gp;
+        if (wr) *w = *b; else *b = *w;
+      } else if (field == RG_F_APPLYHASH) {
+        uint64_t *b = (uint64_t *)buf + gp;
+        if (wr) rf->applyHash = *b; else *b = rf->applyHash;
+      } else if (field == RG_F_NEXTINDEX || field == RG_F_MATCHINDEX) {
+        int32_t *w = field == RG_F_NEXTINDEX ? rf->next : rf->match, *b = (int32_t *)buf + gp * P;
+        if (wr) memcpy(w, b, sizeof(int32_t) * (size_t)P); else memcpy(b, w, sizeof(int32_t) * (size_t)P);
+      } else if (field == RG_F_LOGTERM || field == RG_F_SNAPLOGTERM) {
+        int32_t *w = field == RG_F_LOGTERM ? rf->logTerm : rf->snapTerm_, *b = (int32_t *)buf + gp * L;
+        if (wr) memcpy(w, b, sizeof(int32_t) * (size_t)L); else memcpy(b, w, sizeof(int32_t) * (size_t)L);
+      } else {
+        uint64_t *w = field == RG_F_LOGCMD ? rf->logCmd : rf->snapCmd_, *b = (uint64_t *)buf + gp * L;
+        if (wr) memcpy(w, b, sizeof(uint64_t) * (size_t)L); else memcpy(b, w, sizeof(uint64_t) * (size_t)L);
+      }
+    }
+  }
+  if (wr && (field == RG_F_LOGTERM || field == RG_F_LOGCMD || field == RG_F_SNAPLOGTERM || field == RG_F_SNAPLOGCMD))
+    for (int g = 0; g < G; g++) for (int p = 0; p < P; p++) e->groups[g].peer[p].snapSync = 0;   /* arrays no longer known equal */
+  return RG_OK;
+}
+int ro_read_state(ro_engine *e, int32_t field, void *dst, int64_t bytes) { return rw_state(e, field, dst, bytes, 0); }
+int ro_write_state(ro_engine *e, int32_t field, const void *src, int64_t bytes) { return rw_state(e, field, (void *)src, bytes, 1); }
+
+/* order-free digest: sum over every Raft-visible word of H(position, value) */
+static inline uint64_t elem_hash(uint32_t peer, uint32_t field, uint32_t idx, uint64_t v) {
+  return sm64(sm64(((uint64_t)peer << 48) ^ ((uint64_t)field << 32) ^ idx) ^ v);
+}
+int ro_state_hash(ro_engine *e, uint64_t *out, int64_t n) {
+  if (!e || !out || n != e->G) return RG_ERR_ARG;
+  for (int g = 0; g < e->G; g++) {
+    group_t *gr = &e->groups[g];
+    uint64_t s = 0;
+    for (int p = 0; p < e->P; p++) {
+      peer_t *rf = &gr->peer[p];
+      for (int f = 0; f < RG_F_PEER_I32_END; f++) s += elem_hash((uint32_t)p, (uint32_t)f, 0, (uint64_t)(uint32_t)*peer_i32(rf, f));
+      s += elem_hash((uint32_t)p, RG_F_APPLYHASH, 0, rf->applyHash);
+      for (int i = 0; i < e->P; i++) {
+        s += elem_hash((uint32_t)p, RG_F_NEXTINDEX, (uint32_t)i, (uint64_t)(uint32_t)rf->next[i]);
+        s += elem_hash((uint32_t)p, RG_F_MATCHINDEX, (uint32_t)i, (uint64_t)(uint32_t)rf->match[i]);
+      }
+      for (int i = 0; i < rf->logLen && i < e->L; i++) {
+        s += elem_hash((uint32_t)p, RG_F_LOGTERM, (uint32_t)i, (uint64_t)(uint32_t)rf->logTerm[i]);
+        s += elem_hash((uint32_t)p, RG_F_LOGCMD, (uint32_t)i, rf->logCmd[i]);
+      }
+      for (int i = 0; i < rf->snapLen && i < e->L; i++) {
+        s += elem_hash((uint32_t)p, RG_F_SNAPLOGTERM, (uint32_t)i, (uint64_t)(uint32_t)rf->snapTerm_[i]);
+        s += elem_hash((uint32_t)p, RG_F_SNAPLOGCMD, (uint32_t)i, rf->snapCmd_[i]);
+      }
+    }
+    for (int f = RG_F_STARTSEQ; f <= RG_F_GFLAGS; f++) s += elem_hash(255, (uint32_t)f, 0, (uint64_t)(uint32_t)*group_i32(gr, f));
+    for (int i = 1; i <= gr->recMax && i < e->L; i++) s += elem_hash(255, RG_F_APPLYREC, (uint32_t)i, gr->applyRec[i]);
+    out[g] = sm64(s ^ (uint64_t)(e->cfg.group_base + g));
+  }
+  return RG_OK;
+}
+
+int ro_counters(ro_engine *e, uint64_t *out) {
+  if (!e || !out) return RG_ERR_ARG;
+  memcpy(out, e->counters, sizeof e->counters);
+  return RG_OK;
+}
+
+/* Full scan.  Log matching: for two peers holding index i with the same term,
+ * the commands at i and the terms at i-1 must agree (by induction the whole
+ * prefix).  Leader completeness: every index some peer has applied must be in
+ * every live, self-declared leader's log with the applied command. */
+int ro_safety_check(ro_engine *e) {
+  if (!e) return RG_ERR_ARG;
+  for (int g = 0; g < e->G; g++) {
+    group_t *gr = &e->groups[g];
+    for (int a = 0; a < e->P; a++) for (int b = a + 1; b < e->P; b++) {
+      peer_t *x = &gr->peer[a], *y = &gr->peer[b];
+      int n = x->logLen < y->logLen ? x->logLen : y->logLen;
+      for (int i = 1; i < n; i++)
+        if (x->logTerm[i] == y->logTerm[i] && (x->logCmd[i] != y->logCmd[i] || x->logTerm[i - 1] != y->logTerm[i - 1]))
+          gr->flags |= RG_FLAG_LOG_MATCHING;
+    }
+    for (int a = 0; a < e->P; a++) {
+      peer_t *x = &gr->peer[a];
+      if (!is_leader(x)) continue;
+      for (int i = 1; i <= gr->recMax; i++)
+        if (i >= x->logLen || x->logCmd[i] != gr->applyRec[i]) gr->flags |= RG_FLAG_LEADER_COMPLETENESS;
+    }
+  }
+  return RG_OK;
+}
+int ro_safety_flags(ro_engine *e, uint32_t *out) {
+  if (!e || !out) return RG_ERR_ARG;
+  uint32_t o = 0, n = 0;
+  for (int g = 0; g < e->G; g++) { o |= e->groups[g].flags; n += e->groups[g].flags != 0; }
+  out[0] = o; out[1] = n;
+  return RG_OK;
+}
+
+/* Persister blob, layout in include/raftgpu.h */
+int ro_snapshot_export(ro_engine *e, int32_t g, int32_t p, void *buf, int64_t cap, int64_t *size_out) {
+  CHECK_GP(e, g, p);
+  peer_t *rf = &e->groups[g].peer[p];
+  int32_t n = rf->snapHas ? rf->snapLen : 0;
+  int64_t size = rf->snapHas ? 16 + 16 * (int64_t)n : 0;
+  if (size_out) *size_out = size;
+  if (!buf) return RG_OK;
+  if (cap < size) return RG_ERR_ARG;
+  if (!rf->snapHas) return RG_OK;
+  int32_t *h = (int32_t *)buf;
+  h[0] = rf->snapTerm; h[1] = rf->snapVote; h[2] = n; h[3] = 0;
+  for (int i = 0; i < n; i++) {
+    int32_t *t = (int32_t *)((char *)buf + 16 + 16 * (int64_t)i);
+    t[0] = rf->snapTerm_[i]; t[1] = 0;
+    memcpy(t + 2, &rf->snapCmd_[i], 8);
+  }
+  return RG_OK;
+}
+int ro_snapshot_import(ro_engine *e, int32_t g, int32_t p, const void *buf, int64_t size) {
+  CHECK_GP(e, g, p);
+  peer_t *rf = &e->groups[g].peer[p];
+  if (size == 0) { rf->snapHas = 0; rf->snapLen = 0; return RG_OK; }
+  if (!buf || size < 16) return RG_ERR_ARG;
+  const int32_t *h = (const int32_t *)buf;
+  int32_t n = h[2];
+  if (n < 0 || n > e->L || size != 16 + 16 * (int64_t)n) return RG_ERR_ARG;
+  rf->snapTerm = h[0]; rf->snapVote = h[1]; rf->snapLen = n; rf->snapHas = 1;
+  for (int i = 0; i < n; i++) {
+    const int32_t *t = (const int32_t *)((const char *)buf + 16 + 16 * (int64_t)i);
+    rf->snapTerm_[i] = t[0];
+    memcpy(&rf->snapCmd_[i], t + 2, 8);
+  }
+  rf->snapSync = 0;
+  return RG_OK;
+}
