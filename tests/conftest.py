@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    from oracle import binding
+    if os.path.isdir(os.path.join(ROOT, "oracle")) and os.access(os.path.join(ROOT, "oracle"), os.W_OK):
+        try:
+            binding.build()
+        except Exception:
+            pass
+    return binding.load()
