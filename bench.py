@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- group-ticks/s and committed entries/s of the lockstep Raft engine.
+
+A step is one pass of the hot path over one batch of synthetic input: every
+group of the shard is reset to its boot state and advanced through the whole
+seeded tick schedule of the workload in one kernel launch.
+
+Workload at every N (weak scaling, per GPU): 65,536 groups x 5 peers, 1024-entry
+logs, seeded 10 % request loss + 10 % reply loss, rolling partitions every
+100..119 ticks, one client Start per group every 5 ticks up to 1000 entries,
+20,000 ticks.  Rank r owns global groups [r*65536, (r+1)*65536); the seeded
+streams key on the global group id, so results do not depend on N.  The only
+collective is one all-reduce of counters and safety flags per step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+
+
+def workload_config(args, rank):
+    from raft_amd import _abi
+    return _abi.make_config(
+        n_groups=args.groups, n_peers=args.peers, log_cap=args.log_cap, device=int(os.environ.get("LOCAL_RANK", 0)),
+        group_base=rank * args.groups, seed=args.seed,
+        req_drop_permille=args.drop, reply_drop_permille=args.drop,
+        start_period=5, start_first_tick=0, start_max=args.entries,
+        part_period=args.part_period, part_jitter=20 if args.part_period else 0)
+
+
+def algorithmic_bytes(c, P):
+    """Bytes the lockstep model has to move, from the engine's event counters:
+    the 40 B scalar block of every peer once per tick, plus per event: a vote
+    request 64 B, an AppendEntries 124 B + 24 B per entry, one commit scan
+    (4P+4 B) per replication round, 24 B per applied entry, 12 B per persist
+    header and per newly persisted entry, 12 B per appended entry."""
+    rv_delivered = c["rpc_delivered"] - c["ae_delivered"]
+    return (c["group_ticks"] * 40 * P + rv_delivered * 64 + c["ae_delivered"] * 124 + c["entries_replicated"] * 24 +
+            c["ae_rounds"] * (4 * P + 4) + c["entries_applied"] * 24 + c["persists"] * 12 + c["persist_entries"] * 12 +
+            c["entries_started"] * 12)
+
+
+def cpu_baseline(args):
+    """The CPU checker (a port of the reference's logic to the same lockstep
+    schedule) timed on the host cores, on a bounded sample of the workload."""
+    from oracle.binding import OracleEngine
+    from raft_amd import _abi
+    threads = max(1, min(16, os.cpu_count() or 1))
+    groups = args.cpu_groups
+    cfg = workload_config(args, 0)
+    cfg.n_groups = groups
+    o = OracleEngine(cfg)
+    t0 = time.time()
+    o.step_mt(args.ticks, threads)
+    dt = time.time() - t0
+    c = o.counters()
+    o1 = OracleEngine(cfg)
+    one_groups = max(1, groups // threads)
+    cfg1 = workload_config(args, 0)
+    cfg1.n_groups = one_groups
+    o1 = OracleEngine(cfg1)
+    t0 = time.time()
+    o1.step(args.ticks)
+    dt1 = time.time() - t0
+    return {
+        "value": c["group_ticks"] / dt, "unit": "group-ticks/s", "cores": threads, "kind": "port",
+        "sample": "first %d groups of the workload x %d ticks, groups sharded over %d threads" % (groups, args.ticks, threads),
+        "committed_entries_per_s": c["entries_committed"] / dt,
+        "single_thread_value": one_groups * args.ticks / dt1,
+        "go_reference": "not run: no Go toolchain on this host",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--groups", type=int, default=65536, help="groups per GPU")
+    ap.add_argument("--peers", type=int, default=5)
+    ap.add_argument("--log-cap", type=int, default=1024)
+    ap.add_argument("--entries", type=int, default=1000)
+    ap.add_argument("--ticks", type=int, default=20000)
+    ap.add_argument("--drop", type=int, default=100, help="request and reply loss, permille")
+    ap.add_argument("--part-period", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--launch-ticks", type=int, default=0, help="ticks per kernel launch (0 = the whole schedule)")
+    ap.add_argument("--cpu-groups", type=int, default=16384)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raft_amd import Engine, _abi
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    eng = Engine(workload_config(args, rank))
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    launch = args.launch_ticks or args.ticks
+    red = torch.zeros(_abi.N_COUNTERS + 8, dtype=torch.int64, device="cuda")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        eng.reset()
+        done = 0
+        while done < args.ticks:
+            n = min(launch, args.ticks - done)
+            eng.step(n)
+            done += n
+        # counters and safety flags: the only cross-GPU exchange of the path
+        c = eng.counters()
+        fl, nfl = eng.safety_flags()
+        vals = [c[k] for k in _abi.COUNTERS] + [(fl >> b) & 1 for b in range(7)] + [nfl]
+        red.copy_(torch.tensor(vals, dtype=torch.int64), non_blocking=False)
+        if world > 1:
+            dist.all_reduce(red[:_abi.N_COUNTERS], op=dist.ReduceOp.SUM)
+            dist.all_reduce(red[_abi.N_COUNTERS:_abi.N_COUNTERS + 7], op=dist.ReduceOp.MAX)
+            dist.all_reduce(red[_abi.N_COUNTERS + 7:], op=dist.ReduceOp.SUM)
+        return red.tolist()
+
+    for _ in range(args.warmup):
+        one_step()
+    ms0, n0 = eng.step_time_ms()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tot = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ms1, n1 = eng.step_time_ms()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    counters = dict(zip(_abi.COUNTERS, tot[:_abi.N_COUNTERS]))
+    flags = sum(int(b) << i for i, b in enumerate(tot[_abi.N_COUNTERS:_abi.N_COUNTERS + 7]))
+    flagged_groups = int(tot[_abi.N_COUNTERS + 7])
+    group_ticks_per_step = world * args.groups * args.ticks
+
+    # roofline of the tick kernel on this rank: algorithmic bytes of one launch
+    # over its mean duration (HIP events on the launch stream, inside the engine)
+    local_c = eng.counters()
+    launches = max(1, n1 - n0)
+    kernel_ms = (ms1 - ms0) / launches
+    launches_per_step = (args.ticks + launch - 1) // launch
+    bytes_per_launch = algorithmic_bytes(local_c, args.peers) / launches_per_step
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "group_ticks_per_sec", "value": group_ticks_per_step * args.steps / dt, "unit": "group-ticks/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "committed_entries_per_sec": counters["entries_committed"] * args.steps / dt,
+        "config": {
+            "workload": "%d groups/GPU x %d peers, %d-entry logs, %d/1000 request + %d/1000 reply loss, rolling partitions "
+                        "every %d..%d ticks, Start every 5 ticks to %d entries, %d ticks/step" % (
+                            args.groups, args.peers, args.log_cap, args.drop, args.drop, args.part_period,
+                            args.part_period + 19, args.entries, args.ticks),
+            "groups_total": world * args.groups, "peers": args.peers, "ticks_per_step": args.ticks,
+            "ticks_per_launch": launch, "parallelism": "groups sharded x%d, no data-path collective" % world, "seed": args.seed,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "kernel": "k_tick", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "mode": "fused: peer scalars stay in registers across the %d ticks of a launch" % launch,
+        },
+        "safety_flags": flags, "flagged_groups": flagged_groups,
+        "counters_per_step": counters,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,6 +87,7 @@ enum {
   RG_C_TIMEOUTS,            /* follower -> candidate transitions (raft.go:557-561)       */
   RG_C_AE_CONFLICTS,        /* AppendEntries answered with a conflict hint (raft.go:303) */
   RG_C_STEPDOWNS,           /* sender saw a higher term in a reply (raft.go:482,622)     */
+  RG_C_AE_DELIVERED,        /* AppendEntries handler runs (subset of RPC_DELIVERED)      */
   RG_N_COUNTERS
 };
 

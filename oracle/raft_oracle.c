@@ -399,6 +399,7 @@ static void monitor_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t now
         if (out != NET_LOST) {
           append_entries(e, c, g, &g->peer[i], now, &args, rf->logTerm + args.entry_off, rf->logCmd + args.entry_off, &reply);
           c->c[RG_C_RPC_DELIVERED]++;
+          c->c[RG_C_AE_DELIVERED]++;
           if (out == NET_OK) { ok = 1; c->c[RG_C_RPC_REPLIED]++; }
         }
         if (ok) {

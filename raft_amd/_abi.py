@@ -28,7 +28,7 @@ COUNTERS = [
     "group_ticks", "rpc_sent", "rpc_delivered", "rpc_replied", "rv_rounds",
     "elections_won", "ae_rounds", "entries_started", "entries_replicated",
     "entries_committed", "entries_applied", "persists", "persist_entries",
-    "timeouts", "ae_conflicts", "stepdowns",
+    "timeouts", "ae_conflicts", "stepdowns", "ae_delivered",
 ]
 N_COUNTERS = len(COUNTERS)
 

@@ -610,6 +610,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
           if (wantAE) {
             ctr_add(w, RG_C_RPC_SENT, (unsigned)__popc(calledM));
             ctr_add(w, RG_C_RPC_DELIVERED, (unsigned)__popc(ranM));
+            ctr_add(w, RG_C_AE_DELIVERED, (unsigned)__popc(ranM));
             ctr_add(w, RG_C_RPC_REPLIED, (unsigned)__popc(okM));
             if (b < PP) {                                            // raft.go:482-487: voteFor is kept
               r.setState(RG_FOLLOWER);
@@ -1035,7 +1036,7 @@ static int init_state(rg_engine *e) {
   HIPCHK(hipMemcpyAsync(S.rngCtr, rng.data(), nL * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(S.partNext, pn.data(), (size_t)e->Gpad * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
-  e->now = 0; e->stepMs = 0; e->launches = 0; e->derivedDirty = false; e->syncDirty = false;
+  e->now = 0; e->derivedDirty = false; e->syncDirty = false;
   std::fill(e->drained.begin(), e->drained.end(), 0);
   return RG_OK;
 }
@@ -1067,7 +1068,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   e->nLanes = (long long)e->Gpad * e->PP;
   e->cmdOff = (e->P * 4 + 7) & ~7;
   e->rowBytes = (e->cmdOff + e->P * 8 + 15) & ~15;
-  e->ownStream = nullptr; e->dCmd = nullptr; e->dCmdCap = 0;
+  e->ownStream = nullptr; e->dCmd = nullptr; e->dCmdCap = 0; e->stepMs = 0; e->launches = 0;
   if (hipStreamCreateWithFlags(&e->ownStream, hipStreamNonBlocking) != hipSuccess) { delete e; return RG_ERR_HIP; }
   e->stream = e->ownStream;
   DevPtrs &S = e->S;
