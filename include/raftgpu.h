@@ -37,14 +37,16 @@ extern "C" {
 /* ---- lockstep time base (all reference timing literals are multiples of
  * these; src/raft/raft.go:421,524,532-534,567,665,667,675) ---------------- */
 #define RG_TICK_MS            10   /* one tick of simulated time               */
-#define RG_ELECTION_PERIOD     5   /* election loop sleeps 50 ms  (:667)        */
-#define RG_ELECTION_LEADER_EXTRA 1 /* +10 ms when it saw state==2 (:665)        */
-#define RG_MONITOR_POLL        2   /* leader loop idle sleep 20 ms (:524)       */
+#define RG_ELECTION_PERIOD_MS 50   /* election loop sleep         (:667)        */
+#define RG_ELECTION_LEADER_EXTRA_MS 10 /* extra sleep when it saw state==2 (:665) */
+#define RG_MONITOR_POLL_MS    20   /* leader loop idle sleep      (:524)        */
 #define RG_HB_IDLE_MS        100   /* heartbeat gate, idle        (:421)        */
 #define RG_HB_BACKLOG_MS      50   /* heartbeat gate, uncommitted (:421)        */
 #define RG_CANDIDATE_WINDOW_MS 1000/* timeout while candidate     (:567)        */
 #define RG_TIMEOUT_BASE_MS   500   /* nextRandom(): Intn(600)+500 (:532-534)    */
 #define RG_TIMEOUT_SPAN_MS   600
+#define RG_RPC_WAIT_MS        25   /* a Call without a reply costs the sender this wait (:473,:608) */
+#define RG_NET_DELAY_SPAN_MS  27   /* unreliable net: each Call sleeps 0..26 ms (labrpc.go:222)     */
 #define RG_MAX_PEERS           8
 
 /* ---- status codes ------------------------------------------------------ */
@@ -95,7 +97,8 @@ enum {
  * Host layout: per-peer fields int32 [n_groups][n_peers]; per-group fields
  * int32 [n_groups]; matrices int32 [n_groups][n_peers(owner)][n_peers];
  * logs [n_groups][n_peers][log_cap] (int32 terms, uint64 commands).
- * TIMER, HBTIMER, ELNEXT, MONNEXT, PARTNEXT are in ticks, TIMEOUT in ms.   */
+ * TIMER, HBTIMER, ELNEXT, MONNEXT, TIMEOUT are in ms of simulated time
+ * (tick x 10), PARTNEXT in ticks.                                          */
 enum {
   RG_F_TERM = 0, RG_F_VOTE, RG_F_STATE, RG_F_COMMIT, RG_F_APPLIED, RG_F_LOGLEN,
   RG_F_TIMER, RG_F_TIMEOUT, RG_F_HBTIMER, RG_F_STOP, RG_F_CNT, RG_F_DEAD,

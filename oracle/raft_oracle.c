@@ -12,13 +12,19 @@
  *
  *   tick t (10 ms), per group:
  *     1. control   : rolling-partition reshuffle, churn, client Start injection
- *     2. actors    : for p = 0..P-1 (live peers): the election loop iteration
- *                    if its 50/60 ms sleep is over, then the leader loop
- *                    (monitor) if its 20 ms sleep is over.  An RPC is a direct
- *                    call of the target's handler, gated by the network
- *                    outcome (not delivered / handler ran, reply lost / round
- *                    trip), exactly in the reference's sequential fan-out
- *                    order with its break rules.  A round takes no time.
+ *     2. actors    : live peers in cyclic index order from a seeded per-tick
+ *                    start (goroutine scheduling order is arbitrary in the
+ *                    reference; a fixed order phase-locks its 50 ms loops):
+ *                    the election loop iteration if its sleep is over, then
+ *                    the leader loop (monitor) if its sleep is over.  An RPC
+ *                    is a direct call of the target's handler, gated by the
+ *                    network outcome (not delivered / handler ran, reply lost /
+ *                    round trip), exactly in the reference's sequential
+ *                    fan-out order with its break rules.  The handlers of a
+ *                    round all run at the round's tick; the sender is busy for
+ *                    the round's duration: 25 ms for every Call without a
+ *                    reply (raft.go:473,608) plus the unreliable net's 0..26 ms
+ *                    per Call (labrpc.go:222), and its loop resumes after it.
  *     3. apply     : for p = 0..P-1: the apply loop iteration (10 ms period)
  *     4. check     : one-leader-per-term among connected peers
  *
@@ -37,7 +43,7 @@ typedef struct {
   /* Raft struct, src/raft/raft.go:57-86 */
   int32_t dead, term, vote, logLen, commit, applied;
   int32_t next[RG_MAX_PEERS], match[RG_MAX_PEERS];
-  int32_t timer, state, hbTimer, stop, cnt;       /* timer, hbTimer in ticks */
+  int32_t timer, state, hbTimer, stop, cnt;       /* timer, hbTimer in ms of simulated time */
   /* locals of the election goroutine, raft.go:543-547 */
   int32_t timeout, restart, elNext;
   /* the monitor goroutine, raft.go:387-394 */
@@ -95,6 +101,15 @@ static int32_t next_random(group_t *g, int p) {
   peer_t *rf = &g->peer[p];
   uint64_t h = stream_hash(g->key, STREAM_ELECTION, (uint32_t)p, rf->rngCtr++);
   return (int32_t)(h % RG_TIMEOUT_SPAN_MS) + RG_TIMEOUT_BASE_MS;
+}
+
+/* time.Sleep never returns early and overshoots by scheduler slack: the
+ * election loop's 50 ms sleep (raft.go:667) lasts 50..53 ms, seeded.  Without
+ * it every loop of a group has exactly the same period and their phases lock. */
+static int32_t sleep_slack(const group_t *g, int p, int32_t now) {
+  uint32_t h = (uint32_t)g->key ^ ((uint32_t)p * 0x9E3779B1u) ^ ((uint32_t)now * 0x85EBCA6Bu);
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return (int32_t)(h >> 30);
 }
 
 /* ---------------- persist / readPersist --------------------------------- */
@@ -218,15 +233,19 @@ static void append_entries(ro_engine *e, ctr_t *c, group_t *g, peer_t *rf, int32
 /* ---------------- network (labrpc.go:216-307) --------------------------- */
 enum { NET_LOST = 0, NET_REPLY_LOST = 1, NET_OK = 2 };
 
-static int net_outcome(const ro_engine *e, const group_t *g, int s, int j, uint32_t seq) {
+static int net_outcome(const ro_engine *e, const group_t *g, int s, int j, uint32_t seq, int32_t *cost) {
   const peer_t *a = &g->peer[s], *b = &g->peer[j];
+  *cost = RG_RPC_WAIT_MS;
   if (!(a->connected && b->connected && a->side == b->side) || b->dead) return NET_LOST;
   const rg_config *cf = &e->cfg;
-  if (cf->req_drop_permille == 0 && cf->reply_drop_permille == 0 && cf->reply_delay_permille == 0) return NET_OK;
+  if (cf->req_drop_permille == 0 && cf->reply_drop_permille == 0 && cf->reply_delay_permille == 0) { *cost = 0; return NET_OK; }
   uint64_t h = stream_hash(g->key, STREAM_NET, ((uint32_t)s << 8) | (uint32_t)j, seq);
+  int32_t d = (int32_t)((h >> 58) % RG_NET_DELAY_SPAN_MS);                                   /* :222 */
   if ((int32_t)((h & 0xFFFFF) % 1000) < cf->req_drop_permille) return NET_LOST;              /* :226 */
+  if (d >= RG_RPC_WAIT_MS) return NET_REPLY_LOST;                    /* handler runs, the sender has given up */
   if ((int32_t)(((h >> 20) & 0xFFFFF) % 1000) < cf->reply_drop_permille) return NET_REPLY_LOST;   /* :273 */
-  if ((int32_t)(((h >> 40) & 0xFFFFF) % 1000) < cf->reply_delay_permille) return NET_REPLY_LOST;  /* :276 */
+  if ((int32_t)(((h >> 40) & 0x3FFFF) % 1000) < cf->reply_delay_permille) return NET_REPLY_LOST;  /* :276 */
+  *cost = d;
   return NET_OK;
 }
 
@@ -256,7 +275,7 @@ static void election_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t no
   int32_t timer = rf->timer;
   switch (state) {
   case RG_FOLLOWER:
-    if ((now - timer) * RG_TICK_MS > rf->timeout) {                /* :557 */
+    if (now - timer > rf->timeout) {                               /* :557 */
       rf->state = RG_CANDIDATE;
       rf->timeout = next_random(g, me);
       c->c[RG_C_TIMEOUTS]++;
@@ -274,10 +293,12 @@ static void election_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t no
     c->c[RG_C_RV_ROUNDS]++;
     uint32_t seq = rf->roundSeq++;
     int voteCnt = 1;
+    int32_t busy = 0, cost;
     for (int i = 0; i < l && state == RG_CANDIDATE; i++) {
       state = rf->state;
       if (i != me) {
-        int out = net_outcome(e, g, me, i, seq);
+        int out = net_outcome(e, g, me, i, seq, &cost);
+        busy += cost;
         c->c[RG_C_RPC_SENT]++;
         int ok = 0;
         if (out != NET_LOST) {
@@ -309,14 +330,14 @@ static void election_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t no
       if (state == RG_FOLLOWER) {
         rf->timeout = next_random(g, me);                          /* :639 */
       } else if (state == RG_CANDIDATE) {
-        if ((now - rf->timer) * RG_TICK_MS < rf->timeout && 2 * voteCnt > l) {   /* :641 */
+        if (now + busy - rf->timer < rf->timeout && 2 * voteCnt > l) {   /* :641 */
           rf->stop = 0;
           rf->cnt = 0;
           rf->state = RG_LEADER;
-          rf->hbTimer = now;
+          rf->hbTimer = now + busy;
           for (int i = 0; i < l; i++) rf->next[i] = rf->logLen;
           for (int i = 0; i < l; i++) rf->match[i] = 0;
-          rf->monAlive = 1; rf->first = 1; rf->monNext = now;      /* go monitor(rf) */
+          rf->monAlive = 1; rf->first = 1; rf->monNext = now + busy; /* go monitor(rf) */
           c->c[RG_C_ELECTIONS_WON]++;
         } else {
           rf->restart = 1;
@@ -324,11 +345,12 @@ static void election_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t no
       }
     }
     state = RG_CANDIDATE;   /* the switch ran on the value loaded at the top */
-    break;
+    rf->elNext = now + busy + RG_ELECTION_PERIOD_MS + sleep_slack(g, me, now);
+    return;
   }
   default: break;
   }
-  rf->elNext = now + RG_ELECTION_PERIOD + (state == RG_LEADER ? RG_ELECTION_LEADER_EXTRA : 0);
+  rf->elNext = now + RG_ELECTION_PERIOD_MS + (state == RG_LEADER ? RG_ELECTION_LEADER_EXTRA_MS : 0) + sleep_slack(g, me, now);
 }
 
 /* commit rule, raft.go:400-416.  Returns 1 when commitIndex advanced. */
@@ -372,11 +394,12 @@ static void monitor_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t now
     int32_t timer = rf->hbTimer;
     int32_t logLen = rf->logLen;
     int32_t commitIndex = rf->commit;
-    int32_t since = (now - timer) * RG_TICK_MS;
+    int32_t since = now - timer;
     if (rf->first || since >= RG_HB_IDLE_MS || (commitIndex < logLen - 1 && since >= RG_HB_BACKLOG_MS)) {   /* :421 */
       rf->first = 0;
       c->c[RG_C_AE_ROUNDS]++;
       uint32_t seq = rf->roundSeq++;
+      int32_t busy = 0, cost;
       for (int i = 0; i < l; i++) {
         if (!is_leader(rf)) break;                                  /* :424-427 */
         if (i == me) continue;
@@ -393,7 +416,8 @@ static void monitor_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t now
           break;                                                    /* :451-454 */
         }
         rg_append_reply reply = { 0, 0, 0, 0 };
-        int out = net_outcome(e, g, me, i, seq);
+        int out = net_outcome(e, g, me, i, seq, &cost);
+        busy += cost;
         c->c[RG_C_RPC_SENT]++;
         int ok = 0;
         if (out != NET_LOST) {
@@ -425,9 +449,10 @@ static void monitor_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t now
         rf->cnt++;
         if (rf->cnt > 3) rf->stop = 1;
       }
-      rf->hbTimer = now;
+      rf->hbTimer = now + busy;                                     /* :521 */
+      if (busy > 0) { rf->monNext = now + busy; return; }           /* the loop goes on once the waits are over */
     } else {
-      rf->monNext = now + RG_MONITOR_POLL;                          /* :524 */
+      rf->monNext = now + RG_MONITOR_POLL_MS;                       /* :524 */
       return;
     }
   }
@@ -465,7 +490,7 @@ static void start1(ro_engine *e, ctr_t *c, group_t *g, int p, int32_t now) {
 }
 
 /* ---------------- control phase ----------------------------------------- */
-static void control_step(ro_engine *e, ctr_t *c, group_t *g, int32_t now) {
+static void control_step(ro_engine *e, ctr_t *c, group_t *g, int32_t now /* tick */) {
   const rg_config *cf = &e->cfg;
   const int P = e->P;
   /* rolling partitions, kvraft/test_test.go:124-143 + kvraft/config.go:174-186 */
@@ -488,7 +513,7 @@ static void control_step(ro_engine *e, ctr_t *c, group_t *g, int32_t now) {
     }
     if ((int32_t)((h2 & 0xFFFFF) % 1000) < cf->churn_restart_permille) {
       int i = (int)((h2 >> 32) % (uint64_t)P);
-      if (g->peer[i].dead) start1(e, c, g, i, now);
+      if (g->peer[i].dead) start1(e, c, g, i, now * RG_TICK_MS);
       g->peer[i].connected = 1;
     }
     if ((int32_t)((h3 & 0xFFFFF) % 1000) < cf->churn_crash_permille) {
@@ -528,9 +553,19 @@ static void check_leaders(ro_engine *e, group_t *g) {
   }
 }
 
-static void tick_group(ro_engine *e, ctr_t *c, group_t *g, int32_t now) {
-  control_step(e, c, g, now);
-  for (int p = 0; p < e->P; p++) {
+/* first peer of this tick's actor order */
+static int turn_start(const group_t *g, int32_t tick, int P) {
+  uint32_t h = (uint32_t)tick * 0x9E3779B1u + (uint32_t)g->key;
+  h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+  return (int)(((h >> 16) * (uint32_t)P) >> 16);
+}
+
+static void tick_group(ro_engine *e, ctr_t *c, group_t *g, int32_t tick) {
+  const int32_t now = tick * RG_TICK_MS;
+  control_step(e, c, g, tick);
+  const int start = turn_start(g, tick, e->P);
+  for (int q = 0; q < e->P; q++) {
+    int p = start + q; if (p >= e->P) p -= e->P;
     peer_t *rf = &g->peer[p];
     if (rf->dead) continue;
     if (rf->elNext <= now) election_step(e, c, g, p, now);
@@ -681,7 +716,7 @@ int ro_crash(ro_engine *e, int32_t g, int32_t p) { CHECK_GP(e, g, p); crash1(&e-
 int ro_restart(ro_engine *e, int32_t g, int32_t p) {
   CHECK_GP(e, g, p);
   ctr_t c; memset(&c, 0, sizeof c);
-  start1(e, &c, &e->groups[g], p, (int32_t)e->now);
+  start1(e, &c, &e->groups[g], p, (int32_t)e->now * RG_TICK_MS);
   add_counters(e, &c);
   return RG_OK;
 }
@@ -695,7 +730,7 @@ int ro_rpc_request_vote(ro_engine *e, int32_t g, int32_t p, const rg_vote_args *
   CHECK_GP(e, g, p);
   if (!a || !r) return RG_ERR_ARG;
   ctr_t c; memset(&c, 0, sizeof c);
-  request_vote(e, &c, &e->groups[g].peer[p], (int32_t)e->now, a, r);
+  request_vote(e, &c, &e->groups[g].peer[p], (int32_t)e->now * RG_TICK_MS, a, r);
   add_counters(e, &c);
   return RG_OK;
 }
@@ -706,7 +741,7 @@ int ro_rpc_append_entries(ro_engine *e, int32_t g, int32_t p, const rg_append_ar
   if (a->prev_log_index < 0 || a->n_entries < 0 || (int64_t)a->prev_log_index + 1 + a->n_entries > e->L) return RG_ERR_RANGE;
   if (a->n_entries > 0 && (!et || !ec)) return RG_ERR_ARG;
   ctr_t c; memset(&c, 0, sizeof c);
-  append_entries(e, &c, &e->groups[g], &e->groups[g].peer[p], (int32_t)e->now, a,
+  append_entries(e, &c, &e->groups[g], &e->groups[g].peer[p], (int32_t)e->now * RG_TICK_MS, a,
                  et ? et + a->entry_off : NULL, ec ? ec + a->entry_off : NULL, r);
   add_counters(e, &c);
   return RG_OK;

@@ -284,6 +284,11 @@ struct Grp {
     for (int m = 1; m < PP; m <<= 1) { int o = __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, v); v = o > v ? o : v; }
     return v;
   }
+  __device__ int gsum(int v) const {
+#pragma unroll
+    for (int m = 1; m < PP; m <<= 1) v += __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, v);
+    return v;
+  }
   __device__ unsigned gor(unsigned v) const {
 #pragma unroll
     for (int m = 1; m < PP; m <<= 1) v |= (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ m) << 2, (int)v);
@@ -294,15 +299,33 @@ struct Grp {
 __device__ static inline bool wave_any(bool p) { return __ballot(p) != 0ull; }
 __device__ static inline void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-// network outcome of one Call, labrpc.go:216-307: 0 lost, 1 handler ran / reply lost, 2 round trip
-__device__ static inline int net_outcome(const DevCfg &c, u64 key, bool reachable, int s, int j, unsigned seq) {
+// network outcome of one Call, labrpc.go:216-307: 0 lost, 1 handler ran / reply lost, 2 round trip.
+// cost = how long the sender is held: the 25 ms wait without a reply (raft.go:473,608), else the net's delay.
+__device__ static inline int net_outcome(const DevCfg &c, u64 key, bool reachable, int s, int j, unsigned seq, int &cost) {
+  cost = RG_RPC_WAIT_MS;
   if (!reachable) return 0;
-  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) return 2;
+  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) { cost = 0; return 2; }
   u64 h = stream_hash(key, STREAM_NET, ((unsigned)s << 8) | (unsigned)j, seq);
+  int d = (int)((unsigned)(h >> 58) % (unsigned)RG_NET_DELAY_SPAN_MS);
   if ((int)((unsigned)(h & 0xFFFFF) % 1000u) < c.reqDrop) return 0;
+  if (d >= RG_RPC_WAIT_MS) return 1;
   if ((int)((unsigned)((h >> 20) & 0xFFFFF) % 1000u) < c.replyDrop) return 1;
-  if ((int)((unsigned)((h >> 40) & 0xFFFFF) % 1000u) < c.replyDelay) return 1;
+  if ((int)((unsigned)((h >> 40) & 0x3FFFF) % 1000u) < c.replyDelay) return 1;
+  cost = d;
   return 2;
+}
+
+// scheduler slack of the election loop's 50 ms sleep: 0..3 ms, seeded
+__device__ static inline int sleep_slack(u64 key, int p, int now) {
+  unsigned h = (unsigned)key ^ ((unsigned)p * 0x9E3779B1u) ^ ((unsigned)now * 0x85EBCA6Bu);
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return (int)(h >> 30);
+}
+// first peer of a tick's actor order
+__device__ static inline int turn_start(u64 key, int tick, int P) {
+  unsigned h = (unsigned)tick * 0x9E3779B1u + (unsigned)key;
+  h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+  return (int)(((h >> 16) * (unsigned)P) >> 16);
 }
 
 // commit rule, raft.go:400-416, in closed form: the floor(P/2)-th largest
@@ -351,6 +374,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
   unsigned gfl = 0;
 
   for (int t = t0; t < t0 + nticks; t++) {
+    const int now = t * RG_TICK_MS;
     // ------------------------------------------------------------ 1. control
     if (c.partPeriod > 0 && t == partNext) {
       unsigned ep = (unsigned)partEpoch;
@@ -364,7 +388,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
       u64 h1 = stream_hash(key, STREAM_CHURN, it, 0), h2 = stream_hash(key, STREAM_CHURN, it, 1), h3 = stream_hash(key, STREAM_CHURN, it, 2);
       if ((int)((unsigned)(h1 & 0xFFFFF) % 1000u) < c.churnDisc && peer == (int)((h1 >> 32) % (u64)P)) r.flags &= ~F_CONNECTED;
       if ((int)((unsigned)(h2 & 0xFFFFF) % 1000u) < c.churnRestart && valid && peer == (int)((h2 >> 32) % (u64)P)) {
-        if (r.has(F_DEAD)) make_peer(r, lg, sn, peer, L, key, t, w);
+        if (r.has(F_DEAD)) make_peer(r, lg, sn, peer, L, key, now, w);
         r.flags |= F_CONNECTED;
       }
       if ((int)((unsigned)(h3 & 0xFFFFF) % 1000u) < c.churnCrash && peer == (int)((h3 >> 32) % (u64)P) && !r.has(F_DEAD)) {
@@ -406,14 +430,16 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
     // ------------------------------------------------------------ 2. actors
     {
       const bool live = valid && !r.has(F_DEAD);
-      const bool elDue = live && r.elNext <= t;
-      const bool monDue = live && r.has(F_MONALIVE) && r.monNext <= t;
+      const bool elDue = live && r.elNext <= now;
+      const bool monDue = live && r.has(F_MONALIVE) && r.monNext <= now;
+      const int start = turn_start(key, t, P);
+      const int myPos = peer - start + (peer < start ? P : 0);
       bool pend = false, specEl = false, specMon = false;
       if (elDue) {
         int st = r.state();
         if (st == RG_FOLLOWER) {
-          if ((t - r.timer) * RG_TICK_MS > r.timeout) pend = true;
-          else r.elNext = t + RG_ELECTION_PERIOD;          // nothing later in this tick can make it fire
+          if (now - r.timer > r.timeout) pend = true;
+          else r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);   // nothing later in this tick can make it fire
         } else if (st == RG_CANDIDATE) pend = true;
         else specEl = true;
       }
@@ -422,7 +448,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
           if (r.state() == RG_CANDIDATE) pend = true;      // its own round may win first
           else { r.flags &= ~F_MONALIVE; r.monNext = 0; }  // raft.go:526-528
         } else {
-          int since = (t - r.hbTimer) * RG_TICK_MS;
+          int since = now - r.hbTimer;
           bool gate = r.has(F_FIRST) || since >= RG_HB_IDLE_MS || (r.commit < r.logLen - 1 && since >= RG_HB_BACKLOG_MS);
           if (gate || r.has(F_CDIRTY)) pend = true; else specMon = true;
         }
@@ -431,24 +457,26 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
 
       while (wave_any(pend)) {
         const unsigned pm = G.ballot(pend);
-        const int s = pm ? (__ffs((int)pm) - 1) : -1;        // this group's acting peer
+        const unsigned pmHi = pm >> start;                   // cyclic order from this tick's start
+        const int s = pmHi ? (start + __ffs((int)pmHi) - 1) : (pm ? (__ffs((int)pm) - 1) : -1);   // this group's acting peer
+        const int sPos = s - start + (s < start ? P : 0);
         const bool isS = pend && peer == s;
         const int sIdx = s < 0 ? 0 : s;
         // ---------------- election loop iteration, raft.go:548-668
         bool wantRV = false;
-        if (isS && r.elNext <= t) {
+        if (isS && r.elNext <= now) {
           int st = r.state();
           if (st == RG_FOLLOWER) {
-            if ((t - r.timer) * RG_TICK_MS > r.timeout) {
+            if (now - r.timer > r.timeout) {
               r.setState(RG_CANDIDATE);
               r.timeout = next_random(r, key, peer);
               ctr_add(w, RG_C_TIMEOUTS, 1);
             }
-            r.elNext = t + RG_ELECTION_PERIOD;
+            r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);
           } else if (st == RG_CANDIDATE) {
             wantRV = true;
           } else {
-            r.elNext = t + RG_ELECTION_PERIOD + RG_ELECTION_LEADER_EXTRA;
+            r.elNext = now + RG_ELECTION_PERIOD_MS + RG_ELECTION_LEADER_EXTRA_MS + sleep_slack(key, peer, now);
           }
         }
         if (wave_any(wantRV)) {
@@ -456,7 +484,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
           int aLli = 0, aLlt = 0;
           if (wantRV) {
             r.timeout = RG_CANDIDATE_WINDOW_MS;
-            r.timer = t;
+            r.timer = now;
             if (!r.has(F_RESTART)) r.term++; else r.flags &= ~F_RESTART;
             r.vote = peer;
             persist(r, lg, sn, peer, L, w);
@@ -472,7 +500,8 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
           if (wantRV) r.roundSeq++;
           const bool tgt = inR && valid && peer != s;
           const bool reach = tgt && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
-          const int out = tgt ? net_outcome(c, key, reach, s, peer, seq) : 0;
+          int cost = 0;
+          const int out = tgt ? net_outcome(c, key, reach, s, peer, seq, cost) : 0;
           VoteDecision d; d.rTerm = 0; d.touch = d.raise = d.grant = false;
           if (out != 0) {
             int myLT = *lg.termp(r.commit < L ? r.commit : L - 1, peer);
@@ -483,10 +512,11 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
           const bool called = tgt && peer <= b, ran = out != 0 && peer <= b, ok = out == 2 && peer <= b;
           if (ran) {
             const bool wasLead = r.state() == RG_LEADER;
-            commit_vote(r, d, T, s, t, lg, sn, peer, L, w);
-            if (wasLead && d.touch && peer > s && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
+            commit_vote(r, d, T, s, now, lg, sn, peer, L, w);
+            if (wasLead && d.touch && myPos > sPos && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok), grantM = G.ballot(ok && d.grant);
+          const int busy = G.gsum(called ? cost : 0);
           bool won = false;
           if (wantRV) {
             ctr_add(w, RG_C_RPC_SENT, (unsigned)__popc(calledM));
@@ -503,9 +533,9 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
               won = true;
               r.flags &= ~(F_STOP | F_CNT_MASK);
               r.setState(RG_LEADER);
-              r.hbTimer = t;
+              r.hbTimer = now + busy;
               r.flags |= F_MONALIVE | F_FIRST | F_CDIRTY;
-              r.monNext = t;
+              r.monNext = now + busy;
               int f = r.logLen;
               if (r.lastTerm == r.term) { while (f > 0 && *lg.termp(f - 1, peer) == r.term) f--; }
               r.firstOwn = f;
@@ -513,7 +543,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
             } else {
               r.flags |= F_RESTART;
             }
-            r.elNext = t + RG_ELECTION_PERIOD;
+            r.elNext = now + busy + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);
           }
           const bool grpWon = G.ballot(won) != 0;
           const int lenW = G.shfl(r.logLen, sIdx);
@@ -521,7 +551,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
           wg_fence();
         }
         // ---------------- leader loop, raft.go:395-529, until it sleeps or exits
-        bool monAct = isS && r.has(F_MONALIVE) && r.monNext <= t;
+        bool monAct = isS && r.has(F_MONALIVE) && r.monNext <= now;
         for (;;) {
           bool wantAE = false;
           if (monAct) {
@@ -542,13 +572,13 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
                   persist(r, lg, sn, peer, L, w);
                 }
               }
-              int since = (t - r.hbTimer) * RG_TICK_MS;
+              int since = now - r.hbTimer;
               if (r.has(F_FIRST) || since >= RG_HB_IDLE_MS || (r.commit < r.logLen - 1 && since >= RG_HB_BACKLOG_MS)) {
                 r.flags &= ~F_FIRST;
                 wantAE = true;
                 ctr_add(w, RG_C_AE_ROUNDS, 1);
               } else {
-                r.monNext = t + RG_MONITOR_POLL;
+                r.monNext = now + RG_MONITOR_POLL_MS;
                 monAct = false;
               }
             }
@@ -567,7 +597,8 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
           const int firstOv = ovm ? (__ffs((int)ovm) - 1) : PP;
           const bool tgt2 = tgt && peer < firstOv;
           const bool reach = tgt2 && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
-          const int out = tgt2 ? net_outcome(c, key, reach, s, peer, seq) : 0;
+          int cost = 0;
+          const int out = tgt2 ? net_outcome(c, key, reach, s, peer, seq, cost) : 0;
           const int prev = nx - 1, k = lenS - nx;
           AppendDecision d; d.rTerm = 0; d.ct = 0; d.ci = 0; d.touch = d.match = false;
           int prevTerm = 0;
@@ -584,7 +615,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
             r.setState(RG_FOLLOWER);
             r.vote = s;                                              // raft.go:281
             if (r.term < T) { r.term = T; persist(r, lg, sn, peer, L, w); }
-            r.timer = t;
+            r.timer = now;
             if (d.match) {
               for (int i = nx; i < lenS; i++) { *lg.termp(i, peer) = *lg.termp(i, sIdx); *lg.cmdp(i, peer) = *lg.cmdp(i, sIdx); }
               if (k > 0 && nx < r.snapSync) r.snapSync = nx;
@@ -597,7 +628,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
             } else {
               ctr_add(w, RG_C_AE_CONFLICTS, 1);
             }
-            if (wasLead && peer > s && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
+            if (wasLead && myPos > sPos && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
           }
           // the leader's handling of each reply, done by the replying lane
           if (ok && b != peer) {
@@ -606,6 +637,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
             else nextRow[sIdx * PP + peer] = leader_backoff(lg, sIdx, nx, 0, 0);   // unreachable: a stale-term reply always outranks the sender
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
+          const int busy = G.gsum(called ? cost : 0);
           const int rTermB = G.shfl(d.rTerm, b < PP ? b : 0);
           if (wantAE) {
             ctr_add(w, RG_C_RPC_SENT, (unsigned)__popc(calledM));
@@ -624,15 +656,16 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
               r.setCnt(cn);
               if (cn > 3) r.flags |= F_STOP;
             }
-            r.hbTimer = t;
+            r.hbTimer = now + busy;                                  // raft.go:521
             r.flags |= F_CDIRTY;
+            if (busy > 0) { r.monNext = now + busy; monAct = false; }   // the loop goes on once the waits are over
           }
           wg_fence();
         }
         if (isS) pend = false;
       }
-      if (specEl) r.elNext = t + RG_ELECTION_PERIOD + RG_ELECTION_LEADER_EXTRA;
-      if (specMon) r.monNext = t + RG_MONITOR_POLL;
+      if (specEl) r.elNext = now + RG_ELECTION_PERIOD_MS + RG_ELECTION_LEADER_EXTRA_MS + sleep_slack(key, peer, now);
+      if (specMon) r.monNext = now + RG_MONITOR_POLL_MS;
     }
 
     // ------------------------------------------------------------ 3. apply, raft.go:676-686 + config.go:170-194
@@ -1231,7 +1264,7 @@ static int run_cmds(rg_engine *e, std::vector<HostCmd> &cmds) {
   for (int lv = 0; lv <= maxLevel; lv++) {
     int cnt = (int)(startOf[lv + 1] - startOf[lv]);
     if (cnt == 0) continue;
-    hipLaunchKernelGGL(k_host_cmds, dim3((cnt + 127) / 128), dim3(128), 0, e->stream, e->S, e->dc, e->PP, e->dCmd + startOf[lv], cnt, (int)e->now);
+    hipLaunchKernelGGL(k_host_cmds, dim3((cnt + 127) / 128), dim3(128), 0, e->stream, e->S, e->dc, e->PP, e->dCmd + startOf[lv], cnt, (int)e->now * RG_TICK_MS);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemcpyAsync(sorted.data(), e->dCmd, n * sizeof(HostCmd), hipMemcpyDeviceToHost, e->stream));
@@ -1457,7 +1490,7 @@ extern "C" int rg_rpc_request_vote(rg_engine *e, int64_t n, const int32_t *group
   for (size_t lv = 0; lv + 1 < startOf.size(); lv++) {
     int cnt = (int)(startOf[lv + 1] - startOf[lv]);
     if (!cnt) continue;
-    hipLaunchKernelGGL(k_rpc_vote, dim3((cnt + 127) / 128), dim3(128), 0, e->stream, e->S, e->dc, e->PP, dg, dp, dord + startOf[lv], cnt, da, dr, (int)e->now);
+    hipLaunchKernelGGL(k_rpc_vote, dim3((cnt + 127) / 128), dim3(128), 0, e->stream, e->S, e->dc, e->PP, dg, dp, dord + startOf[lv], cnt, da, dr, (int)e->now * RG_TICK_MS);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemcpyAsync(replies, dr, n * sizeof(rg_vote_reply), hipMemcpyDeviceToHost, e->stream));
@@ -1498,7 +1531,7 @@ extern "C" int rg_rpc_append_entries(rg_engine *e, int64_t n, const int32_t *gro
   for (size_t lv = 0; lv + 1 < startOf.size(); lv++) {
     int cnt = (int)(startOf[lv + 1] - startOf[lv]);
     if (!cnt) continue;
-    hipLaunchKernelGGL(k_rpc_append, dim3((cnt + 127) / 128), dim3(128), 0, e->stream, e->S, e->dc, e->PP, dg, dp, dord + startOf[lv], cnt, da, dt, dcm, dr, (int)e->now);
+    hipLaunchKernelGGL(k_rpc_append, dim3((cnt + 127) / 128), dim3(128), 0, e->stream, e->S, e->dc, e->PP, dg, dp, dord + startOf[lv], cnt, da, dt, dcm, dr, (int)e->now * RG_TICK_MS);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemcpyAsync(replies, dr, n * sizeof(rg_append_reply), hipMemcpyDeviceToHost, e->stream));

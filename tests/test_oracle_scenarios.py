@@ -1,0 +1,42 @@
+"""The reference's own Lab 2A/2B/2C tests (src/raft/test_test.go), in tick
+units, against the CPU checker.  They pin the checker to the outcomes the
+reference's tests assert.  Two scenarios end the way the reference's code
+dictates rather than the way its test hopes; each says why."""
+import pytest
+
+from raft_amd import _abi
+from raft_amd.harness import TestFailure
+from tests import scenarios
+
+PASSING = [n for n in scenarios.ALL if n not in ("ReElection2A", "Figure8Unreliable2C")]
+
+
+@pytest.fixture
+def mk(oracle_lib):
+    from oracle.binding import OracleEngine
+    return lambda **kw: OracleEngine(_abi.make_config(**kw))
+
+
+@pytest.mark.parametrize("name", PASSING)
+def test_scenario(mk, name):
+    scenarios.ALL[name](mk)
+
+
+def test_reelection_split_vote_never_resolves(mk):
+    """TestReElection2A up to 'no leader without quorum' (test_test.go:60-76) holds.  The next step
+    cannot: the two peers left without a quorum both became candidates of the same term and voted for
+    themselves, and a failed candidate retries the SAME term for ever (restart, raft.go:569-573,660),
+    so once they can talk again neither can collect a second vote until a third peer joins."""
+    with pytest.raises(TestFailure, match="expected one leader, got none"):
+        scenarios.reelection_2a(mk)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_figure8_unreliable(mk, seed):
+    """TestFigure8Unreliable2C either completes or stops on the tester's 'commit index=' error: the
+    reference elects on commitIndex (raft.go:218-219), so an applied entry can be overwritten.
+    Anything else (lost agreement, out-of-order apply) is a failure."""
+    try:
+        scenarios.figure8_unreliable_2c(mk, seed=seed)
+    except TestFailure as ex:
+        assert "commit index=" in str(ex) or "committed values do not match" in str(ex)
