@@ -30,9 +30,10 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 
 def workload_config(args, rank):
     from raft_amd import _abi
+    from raft_amd.distributed import shard_base
     return _abi.make_config(
         n_groups=args.groups, n_peers=args.peers, log_cap=args.log_cap, device=int(os.environ.get("LOCAL_RANK", 0)),
-        group_base=rank * args.groups, seed=args.seed,
+        group_base=shard_base(rank, args.groups), seed=args.seed,
         req_drop_permille=args.drop, reply_drop_permille=args.drop,
         start_period=5, start_first_tick=0, start_max=args.entries,
         part_period=args.part_period, part_jitter=20 if args.part_period else 0)
@@ -115,7 +116,7 @@ def main():
     eng = Engine(workload_config(args, rank))
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     launch = args.launch_ticks or args.ticks
-    red = torch.zeros(_abi.N_COUNTERS + 8, dtype=torch.int64, device="cuda")
+    from raft_amd.distributed import all_reduce_summary
 
     def barrier():
         if world > 1:
@@ -130,15 +131,8 @@ def main():
             eng.step(n)
             done += n
         # counters and safety flags: the only cross-GPU exchange of the path
-        c = eng.counters()
         fl, nfl = eng.safety_flags()
-        vals = [c[k] for k in _abi.COUNTERS] + [(fl >> b) & 1 for b in range(7)] + [nfl]
-        red.copy_(torch.tensor(vals, dtype=torch.int64), non_blocking=False)
-        if world > 1:
-            dist.all_reduce(red[:_abi.N_COUNTERS], op=dist.ReduceOp.SUM)
-            dist.all_reduce(red[_abi.N_COUNTERS:_abi.N_COUNTERS + 7], op=dist.ReduceOp.MAX)
-            dist.all_reduce(red[_abi.N_COUNTERS + 7:], op=dist.ReduceOp.SUM)
-        return red.tolist()
+        return all_reduce_summary(eng.counters(), fl, nfl, torch.device("cuda", local))
 
     for _ in range(args.warmup):
         one_step()
@@ -155,9 +149,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    counters = dict(zip(_abi.COUNTERS, tot[:_abi.N_COUNTERS]))
-    flags = sum(int(b) << i for i, b in enumerate(tot[_abi.N_COUNTERS:_abi.N_COUNTERS + 7]))
-    flagged_groups = int(tot[_abi.N_COUNTERS + 7])
+    counters, flags, flagged_groups = tot
     group_ticks_per_step = world * args.groups * args.ticks
 
     # roofline of the tick kernel on this rank: algorithmic bytes of one launch
