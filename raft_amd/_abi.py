@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libraftgpu.so")
+LIB_PATH = os.environ.get("RAFTGPU_LIB") or os.path.join(HERE, "lib", "libraftgpu.so")   # env override: A/B builds
 
 # ---- constants mirrored from include/raftgpu.h ---------------------------
 TICK_MS = 10

@@ -133,14 +133,18 @@ struct Lane {
 };
 
 // Addressing of one group's log rows.
+// base is wave-uniform in the tick kernel (the block's first group), off the lane's
+// 32-bit byte offset from it, so accesses use scalar-base + vector-offset addressing.
 struct Rows {
-  char *base; int rowBytes, cmdOff;
-  __device__ int *termp(int i, int col) const { return (int *)(base + (size_t)i * rowBytes) + col; }
-  __device__ u64 *cmdp(int i, int col) const { return (u64 *)(base + (size_t)i * rowBytes + cmdOff) + col; }
+  char *base; unsigned off; int rowBytes, cmdOff;
+  __device__ int *termp(int i, int col) const { return (int *)(base + (size_t)(off + (unsigned)i * (unsigned)rowBytes + (unsigned)col * 4u)); }
+  __device__ u64 *cmdp(int i, int col) const { return (u64 *)(base + (size_t)(off + (unsigned)i * (unsigned)rowBytes + (unsigned)cmdOff + (unsigned)col * 8u)); }
 };
 __device__ static inline Rows rows_of(char *arr, const DevCfg &c, int g) {
-  Rows r; r.base = arr + (size_t)g * c.L * c.rowBytes; r.rowBytes = c.rowBytes; r.cmdOff = c.cmdOff; return r;
+  Rows r; r.base = arr + (size_t)g * c.L * c.rowBytes; r.off = 0; r.rowBytes = c.rowBytes; r.cmdOff = c.cmdOff; return r;
 }
+// the arrays the tick loop itself touches; everything else is read once and written once
+struct HotPtrs { char *logRows, *snapRows; int *nextIdx, *matchIdx; u64 *applyRec; };
 
 __device__ static inline void ctr_add(WaveCtr *w, int which, unsigned v) { atomicAdd(&w->c[which], v); }
 
@@ -348,7 +352,10 @@ __device__ static inline int majority_index(const int (&m)[PP], int P, int me) {
 }
 
 template <int PP>
-__global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int nticks) {
+#ifndef RG_TICK_WAVES
+#define RG_TICK_WAVES 4   // waves per SIMD the register allocation must allow
+#endif
+__global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
   __shared__ WaveCtr sctr[4];
   const Grp<PP> G;
   const int wave = (int)(threadIdx.x >> 6);
@@ -361,17 +368,38 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
   const int peer = G.peer;
   const bool valid = g < c.G && peer < c.P;
   const int P = c.P, L = c.L;
-  const int gq = g < c.G ? g : 0;     // in-range group for address arithmetic of idle lanes
-  const Rows lg = rows_of(S.logRows, c, gq), sn = rows_of(S.snapRows, c, gq);
-  int *const nextRow = S.nextIdx + (size_t)gq * PP * PP;    // [owner][j]
-  int *const matchRow = S.matchIdx + (size_t)gq * PP * PP;
-  u64 *const rec = S.applyRec + (size_t)gq * L;
+  constexpr int GPB = 256 / PP;                               // groups per block
+  const int g0 = (int)blockIdx.x * GPB;                        // the block's first group: always < G
+  const unsigned gLoc = g < c.G ? (unsigned)(g - g0) : 0u;     // in-range group for address arithmetic of idle lanes
+  const int gq = g0 + (int)gLoc;
+  Rows lg, sn;
+  lg.base = H.logRows + (size_t)g0 * L * c.rowBytes; lg.off = gLoc * (unsigned)L * (unsigned)c.rowBytes; lg.rowBytes = c.rowBytes; lg.cmdOff = c.cmdOff;
+  sn = lg; sn.base = H.snapRows + (size_t)g0 * L * c.rowBytes;
+  int *const nextBlk = H.nextIdx + (size_t)g0 * PP * PP;       // uniform; rows [group][owner][j]
+  int *const matchBlk = H.matchIdx + (size_t)g0 * PP * PP;
+  const unsigned mOff = gLoc * (unsigned)(PP * PP);
+#define nextRow(i) nextBlk[mOff + (unsigned)(i)]
+#define matchRow(i) matchBlk[mOff + (unsigned)(i)]
+  u64 *const recBlk = H.applyRec + (size_t)g0 * L;
+  const unsigned rOff = gLoc * (unsigned)L;
+#define rec(i) recBlk[rOff + (unsigned)(i)]
   const u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
   Lane r;
-  r.load(S, gl);
-  int startSeq = S.startSeq[gq], partNext = S.partNext[gq], partEpoch = S.partEpoch[gq], recMax = S.recMax[gq];
+  r.load(*Sp, gl);
+  int startSeq = Sp->startSeq[gq], partNext = Sp->partNext[gq], partEpoch = Sp->partEpoch[gq], recMax = Sp->recMax[gq];
   unsigned gfl = 0;
+  // next ticks of the periodic control events (kept as counters: no division in the loop)
+  int nextStartTick = 0x7fffffff, nextChurnTick = 0x7fffffff, churnIt = 0;
+  if (c.startPeriod > 0) {
+    nextStartTick = c.startFirst;
+    if (t0 > c.startFirst) nextStartTick += (t0 - c.startFirst + c.startPeriod - 1) / c.startPeriod * c.startPeriod;
+  }
+  if (c.churnPeriod > 0) {
+    int from = t0 > 1 ? t0 : 1;
+    churnIt = (from + c.churnPeriod - 1) / c.churnPeriod;
+    nextChurnTick = churnIt * c.churnPeriod;
+  }
 
   for (int t = t0; t < t0 + nticks; t++) {
     const int now = t * RG_TICK_MS;
@@ -383,8 +411,9 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
       partNext = t + c.partPeriod + (c.partJitter > 0 ? (int)(h % (u64)c.partJitter) : 0);
       partEpoch++;
     }
-    if (c.churnPeriod > 0 && t > 0 && t % c.churnPeriod == 0) {      // test_test.go:893-919
-      unsigned it = (unsigned)(t / c.churnPeriod);
+    if (t == nextChurnTick) {                                        // test_test.go:893-919
+      unsigned it = (unsigned)churnIt;
+      churnIt++; nextChurnTick += c.churnPeriod;
       u64 h1 = stream_hash(key, STREAM_CHURN, it, 0), h2 = stream_hash(key, STREAM_CHURN, it, 1), h3 = stream_hash(key, STREAM_CHURN, it, 2);
       if ((int)((unsigned)(h1 & 0xFFFFF) % 1000u) < c.churnDisc && peer == (int)((h1 >> 32) % (u64)P)) r.flags &= ~F_CONNECTED;
       if ((int)((unsigned)(h2 & 0xFFFFF) % 1000u) < c.churnRestart && valid && peer == (int)((h2 >> 32) % (u64)P)) {
@@ -396,7 +425,8 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
         r.flags |= F_DEAD;
       }
     }
-    if (c.startPeriod > 0 && t >= c.startFirst && (t - c.startFirst) % c.startPeriod == 0) {
+    if (t == nextStartTick) {
+      nextStartTick += c.startPeriod;
       // client Starts: config.go:436-451 (first connected leader) / test_test.go:697-703 (every leader)
       bool cand = valid && r.isLeader() && (c.startMode == RG_START_ALL || r.has(F_CONNECTED));
       if (wave_any(cand)) {
@@ -547,7 +577,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
           }
           const bool grpWon = G.ballot(won) != 0;
           const int lenW = G.shfl(r.logLen, sIdx);
-          if (grpWon && valid) { nextRow[sIdx * PP + peer] = lenW; matchRow[sIdx * PP + peer] = 0; }
+          if (grpWon && valid) { nextRow(sIdx * PP + peer) = lenW; matchRow(sIdx * PP + peer) = 0; }
           wg_fence();
         }
         // ---------------- leader loop, raft.go:395-529, until it sleeps or exits
@@ -560,7 +590,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
               if (r.has(F_CDIRTY)) {
                 r.flags &= ~F_CDIRTY;
                 int m[PP];
-                const int4 *mr = (const int4 *)(matchRow + peer * PP);
+                const int4 *mr = (const int4 *)(&matchRow(peer * PP));
                 { int4 a = mr[0]; m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; }
                 if constexpr (PP == 8) { int4 bq = mr[1]; m[4] = bq.x; m[5] = bq.y; m[6] = bq.z; m[7] = bq.w; }
                 int N = majority_index<PP>(m, P, peer);
@@ -592,7 +622,7 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
           const unsigned fS = G.shflu(r.flags, sIdx);
           if (wantAE) r.roundSeq++;
           const bool tgt = inR && valid && peer != s;
-          int nx = tgt ? nextRow[sIdx * PP + peer] : 0;
+          int nx = tgt ? nextRow(sIdx * PP + peer) : 0;
           const unsigned ovm = G.ballot(tgt && nx > lenS);           // raft.go:451-454 ends the round
           const int firstOv = ovm ? (__ffs((int)ovm) - 1) : PP;
           const bool tgt2 = tgt && peer < firstOv;
@@ -632,9 +662,8 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
           }
           // the leader's handling of each reply, done by the replying lane
           if (ok && b != peer) {
-            if (d.match) { nextRow[sIdx * PP + peer] = lenS; matchRow[sIdx * PP + peer] = lenS - 1; }
-            else if (d.touch) nextRow[sIdx * PP + peer] = leader_backoff(lg, sIdx, nx, d.ct, d.ci);
-            else nextRow[sIdx * PP + peer] = leader_backoff(lg, sIdx, nx, 0, 0);   // unreachable: a stale-term reply always outranks the sender
+            if (d.match) { nextRow(sIdx * PP + peer) = lenS; matchRow(sIdx * PP + peer) = lenS - 1; }
+            else nextRow(sIdx * PP + peer) = leader_backoff(lg, sIdx, nx, d.ct, d.ci);   // a stale-term reply would have ended the round
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
           const int busy = G.gsum(called ? cost : 0);
@@ -687,11 +716,11 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
         const u64 cmdFirst = G.shfl64(cmd, first);
         if (mm) {
           if (i <= recMax) {
-            if (mine && rec[i < L ? i : L - 1] != cmd) gfl |= RG_FLAG_STATE_MACHINE;
+            if (mine && rec(i < L ? i : L - 1) != cmd) gfl |= RG_FLAG_STATE_MACHINE;
           } else {
             if (mine && peer == first) {
               if (i != recMax + 1) gfl |= RG_FLAG_APPLY_ORDER;
-              rec[i < L ? i : L - 1] = cmd;
+              rec(i < L ? i : L - 1) = cmd;
             }
             if (mine && cmd != cmdFirst) gfl |= RG_FLAG_STATE_MACHINE;
             recMax = i;
@@ -715,14 +744,17 @@ __global__ __launch_bounds__(256) void k_tick(DevPtrs S, DevCfg c, int t0, int n
     }
   }
 
-  r.store(S, gl);
+#undef nextRow
+#undef matchRow
+#undef rec
+  r.store(*Sp, gl);
   gfl = G.gor(gfl);
   if (valid && peer == 0) {
-    S.startSeq[g] = startSeq; S.partNext[g] = partNext; S.partEpoch[g] = partEpoch; S.recMax[g] = recMax;
-    if (gfl) S.gflags[g] |= gfl;
+    Sp->startSeq[g] = startSeq; Sp->partNext[g] = partNext; Sp->partEpoch[g] = partEpoch; Sp->recMax[g] = recMax;
+    if (gfl) Sp->gflags[g] |= gfl;
   }
   __syncthreads();
-  if (G.lane < RG_N_COUNTERS && w->c[G.lane]) atomicAdd((unsigned long long *)&S.counters[G.lane], (unsigned long long)w->c[G.lane]);
+  if (G.lane < RG_N_COUNTERS && w->c[G.lane]) atomicAdd((unsigned long long *)&Sp->counters[G.lane], (unsigned long long)w->c[G.lane]);
 }
 
 // ---------------------------------------------------------------- host-verb kernels
@@ -952,6 +984,8 @@ struct rg_engine {
   int G, P, L, PP, Gpad, rowBytes, cmdOff;
   long long nLanes;
   DevPtrs S;
+  DevPtrs *dS;          // device copy of S: the tick kernel reads the cold pointers through it
+  HotPtrs H;
   DevCfg dc;
   std::vector<void *> allocs;
   hipStream_t ownStream, stream;
@@ -1125,6 +1159,8 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (rc != RG_OK) { free_engine(e); return rc; }
   e->drained.assign((size_t)e->G * e->P, 0);
   fill_devcfg(e);
+  e->H.logRows = S.logRows; e->H.snapRows = S.snapRows; e->H.nextIdx = S.nextIdx; e->H.matchIdx = S.matchIdx; e->H.applyRec = S.applyRec;
+  if (dalloc(e, &e->dS, 1) != RG_OK || hipMemcpy(e->dS, &e->S, sizeof(DevPtrs), hipMemcpyHostToDevice) != hipSuccess) { free_engine(e); return RG_ERR_NOMEM; }
   rc = init_state(e);
   if (rc != RG_OK) { free_engine(e); return rc; }
   *out = e;
@@ -1189,8 +1225,8 @@ extern "C" int rg_step(rg_engine *e, int32_t n_ticks) {
   HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
   const int blocks = (int)(e->nLanes / 256);
   HIPCHK(hipEventRecord(a, e->stream));
-  if (e->PP == 4) hipLaunchKernelGGL(k_tick<4>, dim3(blocks), dim3(256), 0, e->stream, e->S, e->dc, (int)e->now, (int)n_ticks);
-  else hipLaunchKernelGGL(k_tick<8>, dim3(blocks), dim3(256), 0, e->stream, e->S, e->dc, (int)e->now, (int)n_ticks);
+  if (e->PP == 4) hipLaunchKernelGGL(k_tick<4>, dim3(blocks), dim3(256), 0, e->stream, (const DevPtrs *)e->dS, e->H, e->dc, (int)e->now, (int)n_ticks);
+  else hipLaunchKernelGGL(k_tick<8>, dim3(blocks), dim3(256), 0, e->stream, (const DevPtrs *)e->dS, e->H, e->dc, (int)e->now, (int)n_ticks);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b, e->stream));
   e->pendingEv.push_back(std::make_pair(a, b));
