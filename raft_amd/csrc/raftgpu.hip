@@ -41,7 +41,7 @@ typedef unsigned long long u64;
 struct DevPtrs {
   // per peer, int32 [Gpad*PP]
   int *term, *vote, *flags, *commit, *applied, *logLen, *timer, *timeout, *hbTimer, *elNext, *monNext;
-  int *rngCtr, *roundSeq, *snapTerm, *snapVote, *snapLen, *snapSync, *lastTerm, *firstOwn;
+  int *rngCtr, *roundSeq, *snapTerm, *snapVote, *snapLen, *snapSync, *lastTerm, *firstOwn, *commitTerm;
   u64 *applyHash;
   // leader matrices int32 [Gpad][PP][PP]
   int *nextIdx, *matchIdx;
@@ -77,6 +77,7 @@ struct DevCfg {
 #define F_CNT_SHIFT 10
 #define F_CNT_MASK  (7u << F_CNT_SHIFT)
 #define F_CDIRTY    (1u << 13)   // leader matrices changed since the commit rule last ran
+#define F_SNAPEXT   (1u << 14)   // the persisted log lives in the snapshot rows (imported blob), not in the log rows
 
 #define STREAM_ELECTION 1ull
 #define STREAM_NET      2ull
@@ -98,12 +99,28 @@ __host__ __device__ static inline u64 elem_hash(unsigned peer, unsigned field, u
 }
 
 // per-wave counter block in LDS
-struct WaveCtr { unsigned c[RG_N_COUNTERS]; };
+#define RG_CTR_SLOTS 32   // RG_N_COUNTERS public counters, then profiling slots (builds with -DRG_SECTION_COUNTS)
+struct WaveCtr { unsigned c[RG_CTR_SLOTS]; };
+#ifdef RG_SECTION_COUNTS
+#define SECTION_COUNT(w, i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&(w)->c[RG_N_COUNTERS + (i)], 1u); } while (0)
+#else
+#define SECTION_COUNT(w, i) do { } while (0)
+#endif
+#ifdef RG_STAMPS   // diagnostic builds only: shader cycles per phase of a tick, summed per wave into slots 24..29
+#define STAMP(k) do { unsigned long long _n = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&w->c[24 + (k)], (unsigned)(_n - _stamp)); _stamp = _n; } while (0)
+#define STAMP_INIT unsigned long long _stamp = __builtin_readcyclecounter()
+#else
+#define STAMP(k) do { } while (0)
+#define STAMP_INIT do { } while (0)
+#endif
 
 // Registers of one peer.
 struct Lane {
   int term, vote, commit, applied, logLen, timer, timeout, hbTimer, elNext, monNext;
-  int snapTerm, snapVote, snapLen, snapSync, lastTerm, firstOwn;
+  int snapTerm, snapVote, snapLen, snapSync;
+  // caches of log words (rebuilt by k_derive after host writes): term of the last entry, first index from
+  // which every entry carries the current term, term of the entry at commitIndex
+  int lastTerm, firstOwn, cTerm;
   unsigned flags, rngCtr, roundSeq;
   u64 applyHash;
 
@@ -121,14 +138,14 @@ struct Lane {
     logLen = S.logLen[gl]; timer = S.timer[gl]; timeout = S.timeout[gl]; hbTimer = S.hbTimer[gl]; elNext = S.elNext[gl];
     monNext = S.monNext[gl]; rngCtr = (unsigned)S.rngCtr[gl]; roundSeq = (unsigned)S.roundSeq[gl];
     snapTerm = S.snapTerm[gl]; snapVote = S.snapVote[gl]; snapLen = S.snapLen[gl]; snapSync = S.snapSync[gl];
-    lastTerm = S.lastTerm[gl]; firstOwn = S.firstOwn[gl]; applyHash = S.applyHash[gl];
+    lastTerm = S.lastTerm[gl]; firstOwn = S.firstOwn[gl]; cTerm = S.commitTerm[gl]; applyHash = S.applyHash[gl];
   }
   __device__ void store(const DevPtrs &S, long long gl) const {
     S.term[gl] = term; S.vote[gl] = vote; S.flags[gl] = (int)flags; S.commit[gl] = commit; S.applied[gl] = applied;
     S.logLen[gl] = logLen; S.timer[gl] = timer; S.timeout[gl] = timeout; S.hbTimer[gl] = hbTimer; S.elNext[gl] = elNext;
     S.monNext[gl] = monNext; S.rngCtr[gl] = (int)rngCtr; S.roundSeq[gl] = (int)roundSeq;
     S.snapTerm[gl] = snapTerm; S.snapVote[gl] = snapVote; S.snapLen[gl] = snapLen; S.snapSync[gl] = snapSync;
-    S.lastTerm[gl] = lastTerm; S.firstOwn[gl] = firstOwn; S.applyHash[gl] = applyHash;
+    S.lastTerm[gl] = lastTerm; S.firstOwn[gl] = firstOwn; S.commitTerm[gl] = cTerm; S.applyHash[gl] = applyHash;
   }
 };
 
@@ -148,20 +165,23 @@ struct HotPtrs { char *logRows, *snapRows; int *nextIdx, *matchIdx; u64 *applyRe
 
 __device__ static inline void ctr_add(WaveCtr *w, int which, unsigned v) { atomicAdd(&w->c[which], v); }
 
-// persist(), raft.go:107-123: term, vote and logs[0:commitIndex+1] into the
-// snapshot arrays; only rows not yet known equal are copied.
-__device__ static inline void persist(Lane &r, const Rows &lg, const Rows &sn, int col, int L, WaveCtr *w) {
+// persist(), raft.go:107-123: (term, vote, logs[0:commitIndex+1]).  Every statement of the reference that
+// writes the log is followed by persist() before the peer's lock is released (raft.go:291-300, 354-358),
+// so between handlers the persisted log equals the first snapLen rows of the log itself: the snapshot
+// shares the log rows and persist() moves no entry.  snapSync only keeps the count of entries a copying
+// implementation would have to write (RG_C_PERSIST_ENTRIES).  An imported blob (Persister swap) lives
+// in the separate snapshot rows until the next persist().
+__device__ static inline void persist(Lane &r, int L, WaveCtr *w) {
   int n = r.commit + 1;
   if (n > L) n = L;
   r.snapTerm = r.term;
   r.snapVote = r.vote;
   if (n > r.snapSync) {
-    for (int i = r.snapSync; i < n; i++) { *sn.termp(i, col) = *lg.termp(i, col); *sn.cmdp(i, col) = *lg.cmdp(i, col); }
     ctr_add(w, RG_C_PERSIST_ENTRIES, (unsigned)(n - r.snapSync));
     r.snapSync = n;
   }
   r.snapLen = n;
-  r.flags |= F_SNAPHAS;
+  r.flags = (r.flags | F_SNAPHAS) & ~F_SNAPEXT;
   ctr_add(w, RG_C_PERSISTS, 1);
 }
 
@@ -179,17 +199,19 @@ __device__ static inline void make_peer(Lane &r, const Rows &lg, const Rows &sn,
   r.term = 0; r.vote = -1;
   *lg.termp(0, col) = 0; *lg.cmdp(0, col) = 0;
   r.logLen = 1; r.commit = 0; r.applied = 0; r.timer = now; r.hbTimer = now;
-  r.lastTerm = 0;
+  r.lastTerm = 0; r.cTerm = 0;
   if (r.has(F_SNAPHAS) && r.snapLen >= 1) {
     r.term = r.snapTerm; r.vote = r.snapVote;
     int n = r.snapLen;
-    for (int i = r.snapSync; i < n; i++) { *lg.termp(i, col) = *sn.termp(i, col); *lg.cmdp(i, col) = *sn.cmdp(i, col); }
+    if (r.has(F_SNAPEXT))
+      for (int i = r.snapSync; i < n; i++) { *lg.termp(i, col) = *sn.termp(i, col); *lg.cmdp(i, col) = *sn.cmdp(i, col); }
     if (n > r.snapSync) r.snapSync = n;
     r.logLen = n;
-    persist(r, lg, sn, col, L, w);        // raft.go:147 runs with commitIndex still 0
+    persist(r, L, w);                     // raft.go:147 runs with commitIndex still 0
     r.commit = r.logLen - 1;              // raft.go:148
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     r.lastTerm = *lg.termp(r.logLen - 1, col);
+    r.cTerm = r.lastTerm;
   }
   r.monNext = 0;
   r.timeout = 0;
@@ -208,7 +230,8 @@ __device__ static inline int start_cmd(Lane &r, const Rows &lg, const Rows &sn, 
   if (idx < r.snapSync) r.snapSync = idx;
   r.logLen = idx + 1;
   r.lastTerm = r.term;
-  persist(r, lg, sn, col, L, w);
+  if (idx == r.commit) r.cTerm = r.term;       // only when commitIndex already ran past the log
+  persist(r, L, w);
   ctr_add(w, RG_C_ENTRIES_STARTED, 1);
   return idx;
 }
@@ -229,9 +252,9 @@ __device__ static inline VoteDecision decide_vote(const Lane &r, int myLastTerm,
 __device__ static inline void commit_vote(Lane &r, const VoteDecision &d, int aTerm, int cand, int now,
                                           const Rows &lg, const Rows &sn, int col, int L, WaveCtr *w) {
   if (!d.touch) return;
-  if (d.raise) { r.term = aTerm; r.vote = -1; persist(r, lg, sn, col, L, w); }
+  if (d.raise) { r.term = aTerm; r.vote = -1; persist(r, L, w); }
   r.setState(RG_FOLLOWER);                                  // raft.go:216
-  if (d.grant) { r.vote = cand; persist(r, lg, sn, col, L, w); r.timer = now; }
+  if (d.grant) { r.vote = cand; persist(r, L, w); r.timer = now; }
 }
 
 struct AppendDecision { int rTerm, ct, ci; bool touch, match; };
@@ -360,7 +383,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   const Grp<PP> G;
   const int wave = (int)(threadIdx.x >> 6);
   WaveCtr *w = &sctr[wave];
-  if (G.lane < RG_N_COUNTERS) w->c[G.lane] = 0;
+  if (G.lane < RG_CTR_SLOTS) w->c[G.lane] = 0;
   __syncthreads();
 
   const long long gl = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -403,6 +426,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 
   for (int t = t0; t < t0 + nticks; t++) {
     const int now = t * RG_TICK_MS;
+    STAMP_INIT;
     // ------------------------------------------------------------ 1. control
     if (c.partPeriod > 0 && t == partNext) {
       unsigned ep = (unsigned)partEpoch;
@@ -430,6 +454,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       // client Starts: config.go:436-451 (first connected leader) / test_test.go:697-703 (every leader)
       bool cand = valid && r.isLeader() && (c.startMode == RG_START_ALL || r.has(F_CONNECTED));
       if (wave_any(cand)) {
+        SECTION_COUNT(w, 5);
         bool room = cand && r.logLen < L;
         unsigned mAll = G.ballot(cand), mRoom = G.ballot(room);
         unsigned below = (1u << peer) - 1u;
@@ -457,13 +482,13 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       }
     }
 
+    STAMP(0);
     // ------------------------------------------------------------ 2. actors
     {
       const bool live = valid && !r.has(F_DEAD);
       const bool elDue = live && r.elNext <= now;
       const bool monDue = live && r.has(F_MONALIVE) && r.monNext <= now;
-      const int start = turn_start(key, t, P);
-      const int myPos = peer - start + (peer < start ? P : 0);
+      int start = 0, myPos = 0;
       bool pend = false, specEl = false, specMon = false;
       if (elDue) {
         int st = r.state();
@@ -484,8 +509,11 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         }
       }
       if (pend) { specEl = false; specMon = false; }
+      STAMP(1);
+      if (wave_any(pend)) { start = turn_start(key, t, P); myPos = peer - start + (peer < start ? P : 0); }
 
       while (wave_any(pend)) {
+        SECTION_COUNT(w, 0);
         const unsigned pm = G.ballot(pend);
         const unsigned pmHi = pm >> start;                   // cyclic order from this tick's start
         const int s = pmHi ? (start + __ffs((int)pmHi) - 1) : (pm ? (__ffs((int)pm) - 1) : -1);   // this group's acting peer
@@ -510,6 +538,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           }
         }
         if (wave_any(wantRV)) {
+          SECTION_COUNT(w, 1);
           // candidate prologue, raft.go:566-590
           int aLli = 0, aLlt = 0;
           if (wantRV) {
@@ -517,10 +546,10 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             r.timer = now;
             if (!r.has(F_RESTART)) r.term++; else r.flags &= ~F_RESTART;
             r.vote = peer;
-            persist(r, lg, sn, peer, L, w);
+            persist(r, L, w);
             aLli = r.commit;
-            aLlt = *lg.termp(r.commit < L ? r.commit : L - 1, peer);
-            persist(r, lg, sn, peer, L, w);
+            aLlt = r.cTerm;                                  // logs[commitIndex].Term, raft.go:583
+            persist(r, L, w);
             ctr_add(w, RG_C_RV_ROUNDS, 1);
           }
           const bool inR = G.ballot(wantRV) != 0;
@@ -533,10 +562,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           int cost = 0;
           const int out = tgt ? net_outcome(c, key, reach, s, peer, seq, cost) : 0;
           VoteDecision d; d.rTerm = 0; d.touch = d.raise = d.grant = false;
-          if (out != 0) {
-            int myLT = *lg.termp(r.commit < L ? r.commit : L - 1, peer);
-            d = decide_vote(r, myLT, T, s, lli, llt);
-          }
+          if (out != 0) d = decide_vote(r, r.cTerm, T, s, lli, llt);
           const unsigned sdm = G.ballot(out == 2 && d.rTerm > T);      // raft.go:622
           const int b = sdm ? (__ffs((int)sdm) - 1) : PP;
           const bool called = tgt && peer <= b, ran = out != 0 && peer <= b, ok = out == 2 && peer <= b;
@@ -556,7 +582,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             if (b < PP) {                                          // raft.go:622-627: term is not adopted
               r.setState(RG_FOLLOWER);
               r.vote = -1;
-              persist(r, lg, sn, peer, L, w);
+              persist(r, L, w);
               ctr_add(w, RG_C_STEPDOWNS, 1);
               r.timeout = next_random(r, key, peer);                // raft.go:639
             } else if (2 * voteCnt > P) {                          // raft.go:641-658
@@ -598,8 +624,9 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
                 if (N > r.commit && N >= r.firstOwn) {
                   ctr_add(w, RG_C_ENTRIES_COMMITTED, (unsigned)(N - r.commit));
                   r.commit = N;
+                  r.cTerm = r.term;                                  // N >= firstOwn
                   r.flags |= F_FIRST;
-                  persist(r, lg, sn, peer, L, w);
+                  persist(r, L, w);
                 }
               }
               int since = now - r.hbTimer;
@@ -613,11 +640,13 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               }
             }
           }
+          SECTION_COUNT(w, 2);
           if (!wave_any(wantAE)) break;
+          SECTION_COUNT(w, 3);
           // ---------------- one replication round, raft.go:423-512
           const bool inR = G.ballot(wantAE) != 0;
           const int T = G.shfl(r.term, sIdx), lenS = G.shfl(r.logLen, sIdx), commitS = G.shfl(r.commit, sIdx);
-          const int lastTermS = G.shfl(r.lastTerm, sIdx);
+          const int lastTermS = G.shfl(r.lastTerm, sIdx), firstOwnS = G.shfl(r.firstOwn, sIdx), cTermS = G.shfl(r.cTerm, sIdx);
           const unsigned seq = G.shflu(r.roundSeq, sIdx);
           const unsigned fS = G.shflu(r.flags, sIdx);
           if (wantAE) r.roundSeq++;
@@ -633,8 +662,9 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           AppendDecision d; d.rTerm = 0; d.ct = 0; d.ci = 0; d.touch = d.match = false;
           int prevTerm = 0;
           if (out != 0) {
-            prevTerm = *lg.termp(prev, sIdx);
-            int myPrevTerm = prev < r.logLen ? *lg.termp(prev, peer) : -2;
+            // logs[Prev].Term on both sides, from the caches where they cover it
+            prevTerm = prev == lenS - 1 ? lastTermS : (prev >= firstOwnS ? T : *lg.termp(prev, sIdx));
+            int myPrevTerm = prev == r.logLen - 1 ? r.lastTerm : (prev < r.logLen ? *lg.termp(prev, peer) : -2);
             d = decide_append(r, lg, peer, T, prev, prevTerm, myPrevTerm);
           }
           const unsigned sdm = G.ballot(out == 2 && d.rTerm > T);    // raft.go:482
@@ -644,16 +674,22 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             const bool wasLead = r.state() == RG_LEADER;
             r.setState(RG_FOLLOWER);
             r.vote = s;                                              // raft.go:281
-            if (r.term < T) { r.term = T; persist(r, lg, sn, peer, L, w); }
+            if (r.term < T) { r.term = T; persist(r, L, w); }
             r.timer = now;
             if (d.match) {
               for (int i = nx; i < lenS; i++) { *lg.termp(i, peer) = *lg.termp(i, sIdx); *lg.cmdp(i, peer) = *lg.cmdp(i, sIdx); }
               if (k > 0 && nx < r.snapSync) r.snapSync = nx;
               r.logLen = lenS;
               r.lastTerm = k > 0 ? lastTermS : prevTerm;
+              const int oldCommit = r.commit;
               if (commitS > r.commit) r.commit = (r.logLen - 1 < commitS) ? r.logLen - 1 : commitS;
               if (r.commit > r.logLen - 1) gfl |= RG_FLAG_REF_PANIC;
-              persist(r, lg, sn, peer, L, w);
+              if (r.commit != oldCommit || nx <= r.commit) {          // the entry at commitIndex is new or was rewritten
+                if (r.commit == lenS - 1) r.cTerm = r.lastTerm;
+                else if (r.commit == commitS && commitS < lenS) r.cTerm = cTermS;
+                else { wg_fence(); r.cTerm = *lg.termp(r.commit < L ? r.commit : L - 1, peer); }
+              }
+              persist(r, L, w);
               ctr_add(w, RG_C_ENTRIES_REPLICATED, (unsigned)k);
             } else {
               ctr_add(w, RG_C_AE_CONFLICTS, 1);
@@ -676,7 +712,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             if (b < PP) {                                            // raft.go:482-487: voteFor is kept
               r.setState(RG_FOLLOWER);
               r.term = rTermB;
-              persist(r, lg, sn, peer, L, w);
+              persist(r, L, w);
               ctr_add(w, RG_C_STEPDOWNS, 1);
             }
             int active = 1 + __popc(okM);
@@ -697,10 +733,12 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       if (specMon) r.monNext = now + RG_MONITOR_POLL_MS;
     }
 
+    STAMP(2);
     // ------------------------------------------------------------ 3. apply, raft.go:676-686 + config.go:170-194
     {
       bool act = valid && !r.has(F_DEAD) && r.commit > r.applied;
       while (wave_any(act)) {
+        SECTION_COUNT(w, 4);
         const int i = G.gmin(act ? r.applied + 1 : 0x7fffffff);       // lowest index any peer of the group applies now
         const bool mine = act && r.applied + 1 == i;
         u64 cmd = 0;
@@ -730,11 +768,13 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       }
     }
 
+    STAMP(3);
     // ------------------------------------------------------------ 4. one leader per term, config.go:307-320
     {
       const bool lead = valid && r.has(F_CONNECTED) && r.isLeader();
       const unsigned lm = G.ballot(lead);
       if (wave_any(lead && __popc(lm) > 1)) {
+        SECTION_COUNT(w, 6);
 #pragma unroll
         for (int u = 0; u < PP; u++) {
           int tu = G.shfl(r.term, u);
@@ -742,6 +782,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         }
       }
     }
+    STAMP(4);
   }
 
 #undef nextRow
@@ -754,7 +795,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     if (gfl) Sp->gflags[g] |= gfl;
   }
   __syncthreads();
-  if (G.lane < RG_N_COUNTERS && w->c[G.lane]) atomicAdd((unsigned long long *)&Sp->counters[G.lane], (unsigned long long)w->c[G.lane]);
+  if (G.lane < RG_CTR_SLOTS && w->c[G.lane]) atomicAdd((unsigned long long *)&Sp->counters[G.lane], (unsigned long long)w->c[G.lane]);
 }
 
 // ---------------------------------------------------------------- host-verb kernels
@@ -813,8 +854,7 @@ __global__ void k_rpc_vote(DevPtrs S, DevCfg c, int PP, const int *groups, const
     Lane r; r.load(S, gl);
     if (!r.has(F_DEAD)) {
       rg_vote_args a = args[i];
-      int myLT = *lg.termp(r.commit < c.L ? r.commit : c.L - 1, p);
-      VoteDecision d = decide_vote(r, myLT, a.term, a.candidate, a.last_log_index, a.last_log_term);
+      VoteDecision d = decide_vote(r, r.cTerm, a.term, a.candidate, a.last_log_index, a.last_log_term);
       commit_vote(r, d, a.term, a.candidate, now, lg, sn, p, c.L, &sctr);
       replies[i].term = d.rTerm; replies[i].granted = d.grant ? 1 : 0;
       r.store(S, gl);
@@ -846,7 +886,7 @@ __global__ void k_rpc_append(DevPtrs S, DevCfg c, int PP, const int *groups, con
       if (d.touch) {
         r.setState(RG_FOLLOWER);
         r.vote = a.leader;
-        if (r.term < a.term) { r.term = a.term; persist(r, lg, sn, p, c.L, &sctr); }
+        if (r.term < a.term) { r.term = a.term; persist(r, c.L, &sctr); }
         r.timer = now;
         if (d.match) {
           rep.success = 1;
@@ -857,7 +897,9 @@ __global__ void k_rpc_append(DevPtrs S, DevCfg c, int PP, const int *groups, con
           r.lastTerm = a.n_entries > 0 ? eterms[a.entry_off + a.n_entries - 1] : a.prev_log_term;
           if (a.leader_commit > r.commit) r.commit = (r.logLen - 1 < a.leader_commit) ? r.logLen - 1 : a.leader_commit;
           if (r.commit > r.logLen - 1) gfl |= RG_FLAG_REF_PANIC;
-          persist(r, lg, sn, p, c.L, &sctr);
+          __threadfence();
+          r.cTerm = *lg.termp(r.commit < c.L ? r.commit : c.L - 1, p);
+          persist(r, c.L, &sctr);
           ctr_add(&sctr, RG_C_ENTRIES_REPLICATED, (unsigned)a.n_entries);
         } else {
           rep.conflict_term = d.ct; rep.conflict_first_index = d.ci;
@@ -882,11 +924,26 @@ __global__ void k_derive(DevPtrs S, DevCfg c, int PP, int resetSync) {
   int len = S.logLen[gl], term = S.term[gl];
   int li = len - 1; if (li < 0) li = 0; if (li >= c.L) li = c.L - 1;
   S.lastTerm[gl] = *lg.termp(li, p);
+  { int ci = S.commit[gl]; if (ci < 0) ci = 0; if (ci >= c.L) ci = c.L - 1; S.commitTerm[gl] = *lg.termp(ci, p); }
   int f = len;
   while (f > 0 && f <= c.L && *lg.termp(f - 1, p) == term) f--;
   S.firstOwn[gl] = f;
   S.flags[gl] |= (int)F_CDIRTY;
   if (resetSync) S.snapSync[gl] = 0;   // log and snapshot rows are no longer known equal
+}
+
+// Gives every peer whose persisted log still shares the log rows a private copy in the snapshot rows
+// (before the host overwrites log rows directly).
+__global__ void k_materialize_snap(DevPtrs S, DevCfg c, int PP) {
+  long long gl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int g = (int)(gl / PP), p = (int)(gl % PP);
+  if (g >= c.G || p >= c.P) return;
+  unsigned f = (unsigned)S.flags[gl];
+  if (!(f & F_SNAPHAS) || (f & F_SNAPEXT)) return;
+  const Rows lg = rows_of(S.logRows, c, g), sn = rows_of(S.snapRows, c, g);
+  int n = S.snapLen[gl] < c.L ? S.snapLen[gl] : c.L;
+  for (int i = 0; i < n; i++) { *sn.termp(i, p) = *lg.termp(i, p); *sn.cmdp(i, p) = *lg.cmdp(i, p); }
+  S.flags[gl] = (int)(f | F_SNAPEXT);
 }
 
 // Log matching and leader completeness, one thread per (group, index)
@@ -955,9 +1012,10 @@ __global__ __launch_bounds__(256) void k_hash(DevPtrs S, DevCfg c, u64 *out) {
       s += elem_hash((unsigned)p, RG_F_LOGCMD, (unsigned)i, *lg.cmdp(i, p));
     }
     n = v[RG_F_SNAPLEN] < c.L ? v[RG_F_SNAPLEN] : c.L;
+    const Rows &ps = (f & F_SNAPEXT) ? sn : lg;          // where the persisted log lives
     for (int i = 0; i < n; i++) {
-      s += elem_hash((unsigned)p, RG_F_SNAPLOGTERM, (unsigned)i, (u64)(unsigned)*sn.termp(i, p));
-      s += elem_hash((unsigned)p, RG_F_SNAPLOGCMD, (unsigned)i, *sn.cmdp(i, p));
+      s += elem_hash((unsigned)p, RG_F_SNAPLOGTERM, (unsigned)i, (u64)(unsigned)*ps.termp(i, p));
+      s += elem_hash((unsigned)p, RG_F_SNAPLOGCMD, (unsigned)i, *ps.cmdp(i, p));
     }
     if (p == 0) {
       s += elem_hash(255, RG_F_STARTSEQ, 0, (u64)(unsigned)S.startSeq[g]);
@@ -1063,20 +1121,20 @@ static int init_state(rg_engine *e) {
   const long long nL = e->nLanes;
   DevPtrs &S = e->S;
   hipStream_t st = e->stream;
-  int *zeroed[] = {S.term, S.commit, S.applied, S.timer, S.hbTimer, S.elNext, S.monNext, S.roundSeq, S.snapTerm, S.snapVote, S.snapLen, S.lastTerm};
+  int *zeroed[] = {S.term, S.commit, S.applied, S.timer, S.hbTimer, S.elNext, S.monNext, S.roundSeq, S.snapTerm, S.snapVote, S.snapLen, S.lastTerm, S.commitTerm};
   for (int *p : zeroed) HIPCHK(hipMemsetAsync(p, 0, nL * 4, st));
   HIPCHK(hipMemsetAsync(S.applyHash, 0, nL * 8, st));
   HIPCHK(hipMemsetAsync(S.vote, 0xFF, nL * 4, st));            // -1
   HIPCHK(hipMemsetAsync(S.nextIdx, 0, (size_t)e->Gpad * e->PP * e->PP * 4, st));
   HIPCHK(hipMemsetAsync(S.matchIdx, 0, (size_t)e->Gpad * e->PP * e->PP * 4, st));
   HIPCHK(hipMemsetAsync(S.logRows, 0, (size_t)e->G * e->L * e->rowBytes, st));
-  HIPCHK(hipMemsetAsync(S.snapRows, 0, (size_t)e->G * e->L * e->rowBytes, st));
+  if (S.snapRows) HIPCHK(hipMemsetAsync(S.snapRows, 0, (size_t)e->G * e->L * e->rowBytes, st));
   HIPCHK(hipMemsetAsync(S.applyRec, 0, (size_t)e->G * e->L * 8, st));
   HIPCHK(hipMemsetAsync(S.startSeq, 0, (size_t)e->Gpad * 4, st));
   HIPCHK(hipMemsetAsync(S.partEpoch, 0, (size_t)e->Gpad * 4, st));
   HIPCHK(hipMemsetAsync(S.recMax, 0, (size_t)e->Gpad * 4, st));
   HIPCHK(hipMemsetAsync(S.gflags, 0, (size_t)e->Gpad * 4, st));
-  HIPCHK(hipMemsetAsync(S.counters, 0, RG_N_COUNTERS * 8, st));
+  HIPCHK(hipMemsetAsync(S.counters, 0, RG_CTR_SLOTS * 8, st));
   HIPCHK(hipMemsetAsync(S.flagSummary, 0, 8, st));
   // words that depend on (group, peer): flags, logLen, snapSync, firstOwn, timeout, rngCtr, partNext
   std::vector<int> flags(nL, 0), one(nL, 0), timeout(nL, 0), rng(nL, 0), pn(e->Gpad, 0);
@@ -1116,6 +1174,20 @@ static void free_engine(rg_engine *e) {
   delete e;
 }
 
+// The separate snapshot rows exist only once something needs them: an imported Persister blob or a
+// host write to the log arrays.
+static int ensure_snap_rows(rg_engine *e) {
+  if (e->S.snapRows) return RG_OK;
+  const size_t n = (size_t)e->G * e->L * e->rowBytes;
+  int rc = dalloc(e, &e->S.snapRows, n);
+  if (rc != RG_OK) return rc;
+  HIPCHK(hipMemsetAsync(e->S.snapRows, 0, n, e->stream));
+  e->H.snapRows = e->S.snapRows;
+  HIPCHK(hipMemcpyAsync(e->dS, &e->S, sizeof(DevPtrs), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return RG_OK;
+}
+
 extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (!out || !valid_config(cfg)) return RG_ERR_ARG;
   *out = nullptr;
@@ -1141,20 +1213,20 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   DevPtrs &S = e->S;
   int rc = RG_OK;
   int **i32s[] = {&S.term, &S.vote, &S.flags, &S.commit, &S.applied, &S.logLen, &S.timer, &S.timeout, &S.hbTimer, &S.elNext, &S.monNext,
-                  &S.rngCtr, &S.roundSeq, &S.snapTerm, &S.snapVote, &S.snapLen, &S.snapSync, &S.lastTerm, &S.firstOwn};
+                  &S.rngCtr, &S.roundSeq, &S.snapTerm, &S.snapVote, &S.snapLen, &S.snapSync, &S.lastTerm, &S.firstOwn, &S.commitTerm};
   for (int **p : i32s) if (rc == RG_OK) rc = dalloc(e, p, (size_t)e->nLanes);
   if (rc == RG_OK) rc = dalloc(e, &S.applyHash, (size_t)e->nLanes);
   if (rc == RG_OK) rc = dalloc(e, &S.nextIdx, (size_t)e->Gpad * e->PP * e->PP);
   if (rc == RG_OK) rc = dalloc(e, &S.matchIdx, (size_t)e->Gpad * e->PP * e->PP);
   if (rc == RG_OK) rc = dalloc(e, &S.logRows, (size_t)e->G * e->L * e->rowBytes);
-  if (rc == RG_OK) rc = dalloc(e, &S.snapRows, (size_t)e->G * e->L * e->rowBytes);
+  S.snapRows = nullptr;     // allocated when a blob is first imported (ensure_snap_rows)
   if (rc == RG_OK) rc = dalloc(e, &S.applyRec, (size_t)e->G * e->L);
   if (rc == RG_OK) rc = dalloc(e, &S.startSeq, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.partNext, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.partEpoch, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.recMax, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.gflags, (size_t)e->Gpad);
-  if (rc == RG_OK) rc = dalloc(e, &S.counters, (size_t)RG_N_COUNTERS);
+  if (rc == RG_OK) rc = dalloc(e, &S.counters, (size_t)RG_CTR_SLOTS);
   if (rc == RG_OK) rc = dalloc(e, &S.flagSummary, (size_t)2);
   if (rc != RG_OK) { free_engine(e); return rc; }
   e->drained.assign((size_t)e->G * e->P, 0);
@@ -1426,7 +1498,8 @@ extern "C" int rg_snapshot_export(rg_engine *e, int32_t g, int32_t p, void *buf,
   h[0] = hdr[0]; h[1] = hdr[1]; h[2] = n; h[3] = 0;
   if (n > 0) {
     std::vector<char> rows((size_t)n * e->rowBytes);
-    rc = d2h(e, rows.data(), e->S.snapRows + (size_t)g * e->L * e->rowBytes, rows.size());
+    const char *srcRows = (((unsigned)flags & F_SNAPEXT) && e->S.snapRows) ? e->S.snapRows : e->S.logRows;
+    rc = d2h(e, rows.data(), srcRows + (size_t)g * e->L * e->rowBytes, rows.size());
     if (rc != RG_OK) return rc;
     for (int i = 0; i < n; i++) {
       char *o = (char *)buf + 16 + 16 * (size_t)i;
@@ -1456,6 +1529,8 @@ extern "C" int rg_snapshot_import(rg_engine *e, int32_t g, int32_t p, const void
   const int32_t *h = (const int32_t *)buf;
   const int n = h[2];
   if (n < 0 || n > e->L || size != 16 + 16 * (int64_t)n) return RG_ERR_ARG;
+  rc = ensure_snap_rows(e);
+  if (rc != RG_OK) return rc;
   if (n > 0) {
     std::vector<char> rows((size_t)n * e->rowBytes);
     char *dbase = e->S.snapRows + (size_t)g * e->L * e->rowBytes;
@@ -1469,7 +1544,7 @@ extern "C" int rg_snapshot_import(rg_engine *e, int32_t g, int32_t p, const void
     rc = h2d(e, dbase, rows.data(), rows.size());
     if (rc != RG_OK) return rc;
   }
-  flags |= (int)F_SNAPHAS;
+  flags |= (int)(F_SNAPHAS | F_SNAPEXT);
   int zero = 0;
   rc = h2d(e, e->S.flags + gl, &flags, 4);
   if (rc == RG_OK) rc = h2d(e, e->S.snapTerm + gl, &h[0], 4);
@@ -1677,20 +1752,45 @@ static int rw_state(rg_engine *e, int field, void *buf, int64_t bytes, bool wr) 
   if (field == RG_F_LOGTERM || field == RG_F_SNAPLOGTERM || field == RG_F_LOGCMD || field == RG_F_SNAPLOGCMD) {
     const bool snap = field == RG_F_SNAPLOGTERM || field == RG_F_SNAPLOGCMD;
     const bool isCmd = field == RG_F_LOGCMD || field == RG_F_SNAPLOGCMD;
-    char *dev = snap ? e->S.snapRows : e->S.logRows;
-    // group-sized chunks keep the staging buffer small
+    std::vector<int> flags((size_t)e->nLanes);
+    if (wr) {
+      // a host write to either array first gives every persisted log its own rows, so that writing
+      // the log does not change what is persisted and vice versa
+      rc = ensure_snap_rows(e);
+      if (rc != RG_OK) return rc;
+      hipLaunchKernelGGL(k_materialize_snap, dim3((unsigned)((e->nLanes + 255) / 256)), dim3(256), 0, e->stream, e->S, e->dc, e->PP);
+      HIPCHK(hipGetLastError());
+      if (snap) {
+        rc = d2h(e, flags.data(), e->S.flags, flags.size() * 4);
+        if (rc != RG_OK) return rc;
+        for (auto &f : flags) f |= (int)F_SNAPEXT;
+        rc = h2d(e, e->S.flags, flags.data(), flags.size() * 4);
+        if (rc != RG_OK) return rc;
+      }
+    } else if (snap) {
+      rc = d2h(e, flags.data(), e->S.flags, flags.size() * 4);
+      if (rc != RG_OK) return rc;
+    }
+    char *dev = (snap && wr) ? e->S.snapRows : e->S.logRows;
+    const bool both = snap && !wr && e->S.snapRows != nullptr;   // reading persisted logs: per peer from where they live
+    // group-sized chunks keep the staging buffers small
     const int chunk = std::max(1, (int)std::min<int64_t>(G, (64ll << 20) / ((int64_t)L * e->rowBytes)));
-    std::vector<char> rows((size_t)chunk * L * e->rowBytes);
+    std::vector<char> rows((size_t)chunk * L * e->rowBytes), rows2(both ? rows.size() : 0);
     for (int g0 = 0; g0 < G; g0 += chunk) {
       const int ng = std::min(chunk, G - g0);
       const size_t nb = (size_t)ng * L * e->rowBytes;
       rc = d2h(e, rows.data(), dev + (size_t)g0 * L * e->rowBytes, nb);
       if (rc != RG_OK) return rc;
-      for (int g = 0; g < ng; g++) for (int p = 0; p < P; p++) for (int i = 0; i < L; i++) {
-        char *row = rows.data() + ((size_t)g * L + i) * e->rowBytes;
-        const size_t hi = ((size_t)(g0 + g) * P + p) * L + i;
-        if (isCmd) { u64 *hv = (u64 *)buf + hi; if (wr) memcpy(row + e->cmdOff + 8 * (size_t)p, hv, 8); else memcpy(hv, row + e->cmdOff + 8 * (size_t)p, 8); }
-        else { int32_t *hv = (int32_t *)buf + hi; if (wr) memcpy(row + 4 * (size_t)p, hv, 4); else memcpy(hv, row + 4 * (size_t)p, 4); }
+      if (both) { rc = d2h(e, rows2.data(), e->S.snapRows + (size_t)g0 * L * e->rowBytes, nb); if (rc != RG_OK) return rc; }
+      for (int g = 0; g < ng; g++) for (int p = 0; p < P; p++) {
+        const bool ext = both && (((unsigned)flags[(size_t)(g0 + g) * PP + p]) & F_SNAPEXT);
+        char *base = ext ? rows2.data() : rows.data();
+        for (int i = 0; i < L; i++) {
+          char *row = base + ((size_t)g * L + i) * e->rowBytes;
+          const size_t hi = ((size_t)(g0 + g) * P + p) * L + i;
+          if (isCmd) { u64 *hv = (u64 *)buf + hi; if (wr) memcpy(row + e->cmdOff + 8 * (size_t)p, hv, 8); else memcpy(hv, row + e->cmdOff + 8 * (size_t)p, 8); }
+          else { int32_t *hv = (int32_t *)buf + hi; if (wr) memcpy(row + 4 * (size_t)p, hv, 4); else memcpy(hv, row + 4 * (size_t)p, 4); }
+        }
       }
       if (wr) { rc = h2d(e, dev + (size_t)g0 * L * e->rowBytes, rows.data(), nb); if (rc != RG_OK) return rc; }
     }
@@ -1758,3 +1858,12 @@ extern "C" int rg_device_buffers(rg_engine *e, void **counters_dev, void **flag_
   if (flag_summary_dev) *flag_summary_dev = e->S.flagSummary;
   return RG_OK;
 }
+
+#if defined(RG_SECTION_COUNTS) || defined(RG_STAMPS)
+// profiling builds only: how often each section of k_tick ran, per wave
+extern "C" int rg_debug_section_counts(rg_engine *e, uint64_t *out /* RG_CTR_SLOTS */) {
+  LOCK(e);
+  if (!out) return RG_ERR_ARG;
+  return d2h(e, out, e->S.counters, RG_CTR_SLOTS * 8);
+}
+#endif
