@@ -323,6 +323,58 @@ struct Grp {
   }
 };
 
+// Dense variant for the tick kernel: a group's P peers sit in P adjacent lanes, 64/P whole groups per
+// wave (12 for P = 5) and the 64 % P tail lanes idle, instead of padding every group to a power of two.
+template <int P>
+struct GrpN {
+  static constexpr int GW = 64 / P;          // groups per wave
+  int lane, base, peer;
+  bool inWave;
+  __device__ GrpN() {
+    lane = (int)(threadIdx.x & 63);
+    const int q = lane / P;
+    base = q * P;
+    peer = lane - base;
+    inWave = q < GW;
+  }
+  __device__ int rot(int d) const { int x = peer + d; return base + (x >= P ? x - P : x); }
+  __device__ int shfl(int v, int j) const { return __builtin_amdgcn_ds_bpermute((base + j) << 2, v); }
+  __device__ unsigned shflu(unsigned v, int j) const { return (unsigned)__builtin_amdgcn_ds_bpermute((base + j) << 2, (int)v); }
+  __device__ u64 shfl64(u64 v, int j) const {
+    unsigned lo = shflu((unsigned)v, j), hi = shflu((unsigned)(v >> 32), j);
+    return ((u64)hi << 32) | lo;
+  }
+  __device__ unsigned ballot(bool p) const { return (unsigned)(__ballot(p) >> base) & ((1u << P) - 1u); }
+  // idempotent reductions: doubling rotations cover the group in ceil(log2 P) steps
+  __device__ int gmin(int v) const {
+#pragma unroll
+    for (int d = 1; d < P; d <<= 1) { int o = __builtin_amdgcn_ds_bpermute(rot(d) << 2, v); v = o < v ? o : v; }
+    return v;
+  }
+  __device__ int gmax(int v) const {
+#pragma unroll
+    for (int d = 1; d < P; d <<= 1) { int o = __builtin_amdgcn_ds_bpermute(rot(d) << 2, v); v = o > v ? o : v; }
+    return v;
+  }
+  __device__ unsigned gor(unsigned v) const {
+#pragma unroll
+    for (int d = 1; d < P; d <<= 1) v |= (unsigned)__builtin_amdgcn_ds_bpermute(rot(d) << 2, (int)v);
+    return v;
+  }
+  __device__ int gsum(int v) const {
+    if constexpr ((P & (P - 1)) == 0) {
+#pragma unroll
+      for (int d = 1; d < P; d <<= 1) v += __builtin_amdgcn_ds_bpermute(rot(d) << 2, v);
+      return v;
+    } else {
+      int t = v;
+#pragma unroll
+      for (int d = 1; d < P; d++) t += __builtin_amdgcn_ds_bpermute(rot(d) << 2, v);
+      return t;
+    }
+  }
+};
+
 __device__ static inline bool wave_any(bool p) { return __ballot(p) != 0ull; }
 __device__ static inline void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
@@ -355,46 +407,30 @@ __device__ static inline int turn_start(u64 key, int tick, int P) {
   return (int)(((h >> 16) * (unsigned)P) >> 16);
 }
 
-// commit rule, raft.go:400-416, in closed form: the floor(P/2)-th largest
-// follower matchIndex is the largest N a majority holds; the loop reaches it
-// only if every entry from N to the end carries the current term, i.e.
-// N >= firstOwn.  m[] is the leader's matchIndex row.
-template <int PP>
-__device__ static inline int majority_index(const int (&m)[PP], int P, int me) {
-  const int k = P / 2;   // followers needed besides the leader
-  int best = 0;
-#pragma unroll
-  for (int i = 0; i < PP; i++) {
-    if (i >= P || i == me) continue;
-    int ge = 0;
-#pragma unroll
-    for (int j = 0; j < PP; j++) ge += (j < P && j != me && m[j] >= m[i]) ? 1 : 0;
-    if (ge >= k && m[i] > best) best = m[i];
-  }
-  return best;
-}
-
-template <int PP>
 #ifndef RG_TICK_WAVES
 #define RG_TICK_WAVES 4   // waves per SIMD the register allocation must allow
 #endif
+template <int P>
 __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
+  constexpr int PP = P <= 4 ? 4 : 8;        // stride of a group in the per-peer arrays and matrices in memory
+  constexpr int NONE = 8;                   // "no such peer" for first-set-bit results
+  constexpr int GW = GrpN<P>::GW;
+  constexpr int GPB = 4 * GW;               // groups per 256-thread block
   __shared__ WaveCtr sctr[4];
-  const Grp<PP> G;
+  const GrpN<P> G;
   const int wave = (int)(threadIdx.x >> 6);
   WaveCtr *w = &sctr[wave];
   if (G.lane < RG_CTR_SLOTS) w->c[G.lane] = 0;
   __syncthreads();
 
-  const long long gl = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int g = (int)(gl / PP);
-  const int peer = G.peer;
-  const bool valid = g < c.G && peer < c.P;
-  const int P = c.P, L = c.L;
-  constexpr int GPB = 256 / PP;                               // groups per block
   const int g0 = (int)blockIdx.x * GPB;                        // the block's first group: always < G
-  const unsigned gLoc = g < c.G ? (unsigned)(g - g0) : 0u;     // in-range group for address arithmetic of idle lanes
+  const int g = g0 + wave * GW + (G.lane / P);
+  const int peer = G.peer;
+  const bool valid = G.inWave && g < c.G;
+  const int L = c.L;
+  const unsigned gLoc = valid ? (unsigned)(g - g0) : 0u;       // in-range group for address arithmetic of idle lanes
   const int gq = g0 + (int)gLoc;
+  const long long gl = (long long)(G.inWave ? g : g0) * PP + (G.inWave ? peer : 0);   // slot in the per-peer arrays
   Rows lg, sn;
   lg.base = H.logRows + (size_t)g0 * L * c.rowBytes; lg.off = gLoc * (unsigned)L * (unsigned)c.rowBytes; lg.rowBytes = c.rowBytes; lg.cmdOff = c.cmdOff;
   sn = lg; sn.base = H.snapRows + (size_t)g0 * L * c.rowBytes;
@@ -409,10 +445,17 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   const u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
   Lane r;
-  r.load(*Sp, gl);
+  r.load(*Sp, gl);                       // tail lanes read a valid slot and never write it back
   int startSeq = Sp->startSeq[gq], partNext = Sp->partNext[gq], partEpoch = Sp->partEpoch[gq], recMax = Sp->recMax[gq];
   unsigned gfl = 0;
   // next ticks of the periodic control events (kept as counters: no division in the loop)
+  // Within a launch each lane caches the nextIndex / matchIndex words ONE leader (cOwner) keeps for it; memory is
+  // written through, so the matrices in HBM stay complete for other owners, dumps and digests.
+  int cOwner = -1, cNext = 0, cMatch = 0;
+  // stores to words another lane may read later are drained (vmcnt) only right before such a read
+  bool storesPending = false;
+#define SYNC_STORES() do { if (storesPending) { wg_fence(); storesPending = false; } } while (0)
+  bool chkLeaders = true;      // the one-leader check is re-evaluated only after something changed
   int nextStartTick = 0x7fffffff, nextChurnTick = 0x7fffffff, churnIt = 0;
   if (c.startPeriod > 0) {
     nextStartTick = c.startFirst;
@@ -428,6 +471,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     const int now = t * RG_TICK_MS;
     STAMP_INIT;
     // ------------------------------------------------------------ 1. control
+    if (c.partPeriod > 0 && wave_any(t == partNext)) chkLeaders = true;
     if (c.partPeriod > 0 && t == partNext) {
       unsigned ep = (unsigned)partEpoch;
       r.set(F_SIDE, (stream_hash(key, STREAM_PART, ep, (unsigned)peer + 1) & 1) != 0);
@@ -438,6 +482,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     if (t == nextChurnTick) {                                        // test_test.go:893-919
       unsigned it = (unsigned)churnIt;
       churnIt++; nextChurnTick += c.churnPeriod;
+      chkLeaders = true; storesPending = true;
       u64 h1 = stream_hash(key, STREAM_CHURN, it, 0), h2 = stream_hash(key, STREAM_CHURN, it, 1), h3 = stream_hash(key, STREAM_CHURN, it, 2);
       if ((int)((unsigned)(h1 & 0xFFFFF) % 1000u) < c.churnDisc && peer == (int)((h1 >> 32) % (u64)P)) r.flags &= ~F_CONNECTED;
       if ((int)((unsigned)(h2 & 0xFFFFF) % 1000u) < c.churnRestart && valid && peer == (int)((h2 >> 32) % (u64)P)) {
@@ -470,7 +515,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           startSeq += acc < left ? acc : (left > 0 ? left : 0);
         } else if (startSeq < c.startMax) {
           // peers without room are tried (and flagged) until one accepts
-          int wIdx = mRoom ? (__ffs((int)mRoom) - 1) : PP;
+          int wIdx = mRoom ? (__ffs((int)mRoom) - 1) : NONE;
           if (cand && peer <= wIdx) {
             u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)startSeq);
             start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
@@ -478,7 +523,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           if (mRoom) startSeq++;
           (void)mAll;
         }
-        wg_fence();
+        storesPending = true;
       }
     }
 
@@ -514,6 +559,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 
       while (wave_any(pend)) {
         SECTION_COUNT(w, 0);
+        chkLeaders = true;
         const unsigned pm = G.ballot(pend);
         const unsigned pmHi = pm >> start;                   // cyclic order from this tick's start
         const int s = pmHi ? (start + __ffs((int)pmHi) - 1) : (pm ? (__ffs((int)pm) - 1) : -1);   // this group's acting peer
@@ -564,7 +610,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           VoteDecision d; d.rTerm = 0; d.touch = d.raise = d.grant = false;
           if (out != 0) d = decide_vote(r, r.cTerm, T, s, lli, llt);
           const unsigned sdm = G.ballot(out == 2 && d.rTerm > T);      // raft.go:622
-          const int b = sdm ? (__ffs((int)sdm) - 1) : PP;
+          const int b = sdm ? (__ffs((int)sdm) - 1) : NONE;
           const bool called = tgt && peer <= b, ran = out != 0 && peer <= b, ok = out == 2 && peer <= b;
           if (ran) {
             const bool wasLead = r.state() == RG_LEADER;
@@ -579,7 +625,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             ctr_add(w, RG_C_RPC_DELIVERED, (unsigned)__popc(ranM));
             ctr_add(w, RG_C_RPC_REPLIED, (unsigned)__popc(okM));
             int voteCnt = 1 + __popc(grantM);
-            if (b < PP) {                                          // raft.go:622-627: term is not adopted
+            if (b < NONE) {                                          // raft.go:622-627: term is not adopted
               r.setState(RG_FOLLOWER);
               r.vote = -1;
               persist(r, L, w);
@@ -603,23 +649,38 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           }
           const bool grpWon = G.ballot(won) != 0;
           const int lenW = G.shfl(r.logLen, sIdx);
-          if (grpWon && valid) { nextRow(sIdx * PP + peer) = lenW; matchRow(sIdx * PP + peer) = 0; }
-          wg_fence();
+          if (grpWon && valid) { nextRow(sIdx * PP + peer) = lenW; matchRow(sIdx * PP + peer) = 0; cOwner = s; cNext = lenW; cMatch = 0; }
+          if (wave_any(grpWon)) storesPending = true;
         }
         // ---------------- leader loop, raft.go:395-529, until it sleeps or exits
         bool monAct = isS && r.has(F_MONALIVE) && r.monNext <= now;
         for (;;) {
           bool wantAE = false;
+          // commit rule, raft.go:400-416, in closed form: the largest N held by a majority is the floor(P/2)-th
+          // largest follower matchIndex.  Each follower ranks its own value against the others' (from its cache
+          // of this leader's row, filled from memory on a miss) and the group maximum of the qualifying values
+          // is N.  The loop of the reference reaches N only if every entry from N up carries the current term:
+          // N >= firstOwn.
+          int Nstar = 0;
+          const bool needCR = monAct && r.isLeader() && r.has(F_CDIRTY);
+          if (wave_any(needCR)) {
+            const bool fol = G.ballot(needCR) != 0 && valid && peer != s;
+            if (wave_any(fol && cOwner != s)) {
+              SYNC_STORES();
+              if (fol && cOwner != s) { cNext = nextRow(sIdx * PP + peer); cMatch = matchRow(sIdx * PP + peer); cOwner = s; }
+            }
+            const int mv = fol ? cMatch : -1;
+            int ge = 0;
+#pragma unroll
+            for (int u = 0; u < P; u++) ge += G.shfl(mv, u) >= mv ? 1 : 0;
+            Nstar = G.gmax((fol && ge >= P / 2) ? mv : 0);
+          }
           if (monAct) {
             if (!r.isLeader()) { r.flags &= ~F_MONALIVE; r.monNext = 0; monAct = false; }
             else {
               if (r.has(F_CDIRTY)) {
                 r.flags &= ~F_CDIRTY;
-                int m[PP];
-                const int4 *mr = (const int4 *)(&matchRow(peer * PP));
-                { int4 a = mr[0]; m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; }
-                if constexpr (PP == 8) { int4 bq = mr[1]; m[4] = bq.x; m[5] = bq.y; m[6] = bq.z; m[7] = bq.w; }
-                int N = majority_index<PP>(m, P, peer);
+                int N = Nstar;
                 if (N > r.logLen - 1) N = r.logLen - 1;
                 if (N > r.commit && N >= r.firstOwn) {
                   ctr_add(w, RG_C_ENTRIES_COMMITTED, (unsigned)(N - r.commit));
@@ -651,9 +712,14 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           const unsigned fS = G.shflu(r.flags, sIdx);
           if (wantAE) r.roundSeq++;
           const bool tgt = inR && valid && peer != s;
-          int nx = tgt ? nextRow(sIdx * PP + peer) : 0;
+          if (wave_any(tgt && cOwner != s)) {
+            SYNC_STORES();
+            if (tgt && cOwner != s) { cNext = nextRow(sIdx * PP + peer); cMatch = matchRow(sIdx * PP + peer); cOwner = s; }
+          }
+          if (wave_any(tgt)) SYNC_STORES();                        // the round reads the sender's log rows
+          const int nx = tgt ? cNext : 0;
           const unsigned ovm = G.ballot(tgt && nx > lenS);           // raft.go:451-454 ends the round
-          const int firstOv = ovm ? (__ffs((int)ovm) - 1) : PP;
+          const int firstOv = ovm ? (__ffs((int)ovm) - 1) : NONE;
           const bool tgt2 = tgt && peer < firstOv;
           const bool reach = tgt2 && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
           int cost = 0;
@@ -668,7 +734,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             d = decide_append(r, lg, peer, T, prev, prevTerm, myPrevTerm);
           }
           const unsigned sdm = G.ballot(out == 2 && d.rTerm > T);    // raft.go:482
-          const int b = sdm ? (__ffs((int)sdm) - 1) : PP;
+          const int b = sdm ? (__ffs((int)sdm) - 1) : NONE;
           const bool called = tgt2 && peer <= b, ran = out != 0 && peer <= b, ok = out == 2 && peer <= b;
           if (ran && d.touch) {
             const bool wasLead = r.state() == RG_LEADER;
@@ -687,7 +753,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               if (r.commit != oldCommit || nx <= r.commit) {          // the entry at commitIndex is new or was rewritten
                 if (r.commit == lenS - 1) r.cTerm = r.lastTerm;
                 else if (r.commit == commitS && commitS < lenS) r.cTerm = cTermS;
-                else { wg_fence(); r.cTerm = *lg.termp(r.commit < L ? r.commit : L - 1, peer); }
+                else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); r.cTerm = *lg.termp(r.commit < L ? r.commit : L - 1, peer); }
               }
               persist(r, L, w);
               ctr_add(w, RG_C_ENTRIES_REPLICATED, (unsigned)k);
@@ -698,18 +764,19 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           }
           // the leader's handling of each reply, done by the replying lane
           if (ok && b != peer) {
-            if (d.match) { nextRow(sIdx * PP + peer) = lenS; matchRow(sIdx * PP + peer) = lenS - 1; }
-            else nextRow(sIdx * PP + peer) = leader_backoff(lg, sIdx, nx, d.ct, d.ci);   // a stale-term reply would have ended the round
+            if (d.match) { cNext = lenS; cMatch = lenS - 1; matchRow(sIdx * PP + peer) = cMatch; }
+            else cNext = leader_backoff(lg, sIdx, nx, d.ct, d.ci);   // a stale-term reply would have ended the round
+            nextRow(sIdx * PP + peer) = cNext;
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
           const int busy = G.gsum(called ? cost : 0);
-          const int rTermB = G.shfl(d.rTerm, b < PP ? b : 0);
+          const int rTermB = G.shfl(d.rTerm, b < NONE ? b : 0);
           if (wantAE) {
             ctr_add(w, RG_C_RPC_SENT, (unsigned)__popc(calledM));
             ctr_add(w, RG_C_RPC_DELIVERED, (unsigned)__popc(ranM));
             ctr_add(w, RG_C_AE_DELIVERED, (unsigned)__popc(ranM));
             ctr_add(w, RG_C_RPC_REPLIED, (unsigned)__popc(okM));
-            if (b < PP) {                                            // raft.go:482-487: voteFor is kept
+            if (b < NONE) {                                            // raft.go:482-487: voteFor is kept
               r.setState(RG_FOLLOWER);
               r.term = rTermB;
               persist(r, L, w);
@@ -725,7 +792,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             r.flags |= F_CDIRTY;
             if (busy > 0) { r.monNext = now + busy; monAct = false; }   // the loop goes on once the waits are over
           }
-          wg_fence();
+          storesPending = true;
         }
         if (isS) pend = false;
       }
@@ -737,28 +804,37 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     // ------------------------------------------------------------ 3. apply, raft.go:676-686 + config.go:170-194
     {
       bool act = valid && !r.has(F_DEAD) && r.commit > r.applied;
+      const bool anyApply = wave_any(act);
+      if (anyApply) SYNC_STORES();
       while (wave_any(act)) {
         SECTION_COUNT(w, 4);
-        const int i = G.gmin(act ? r.applied + 1 : 0x7fffffff);       // lowest index any peer of the group applies now
+        // lowest index any peer of the group applies now: nearly always the first pending lane's
+        const unsigned am = G.ballot(act);
+        int i = G.shfl(r.applied + 1, am ? (__ffs((int)am) - 1) : 0);
+        if (wave_any(act && r.applied + 1 < i)) i = G.gmin(act ? r.applied + 1 : 0x7fffffff);
         const bool mine = act && r.applied + 1 == i;
-        u64 cmd = 0;
+        const int ic = i < L ? i : L - 1;
+        u64 cmd = 0, seen = 0;
+        if (mine) {                                   // both loads in flight together
+          cmd = *lg.cmdp(ic, peer);
+          if (i <= recMax) seen = rec(ic);
+        }
+        const unsigned mm = G.ballot(mine);
+        const int first = mm ? (__ffs((int)mm) - 1) : 0;
         if (mine) {
           if (i >= r.logLen) gfl |= RG_FLAG_REF_PANIC;
-          cmd = *lg.cmdp(i < L ? i : L - 1, peer);
           r.applied = i;
           r.applyHash = sm64(r.applyHash ^ cmd ^ ((u64)(unsigned)i << 40));
           ctr_add(w, RG_C_ENTRIES_APPLIED, 1);
         }
-        const unsigned mm = G.ballot(mine);
-        const int first = mm ? (__ffs((int)mm) - 1) : 0;
         const u64 cmdFirst = G.shfl64(cmd, first);
         if (mm) {
           if (i <= recMax) {
-            if (mine && rec(i < L ? i : L - 1) != cmd) gfl |= RG_FLAG_STATE_MACHINE;
+            if (mine && seen != cmd) gfl |= RG_FLAG_STATE_MACHINE;
           } else {
             if (mine && peer == first) {
               if (i != recMax + 1) gfl |= RG_FLAG_APPLY_ORDER;
-              rec(i < L ? i : L - 1) = cmd;
+              rec(ic) = cmd;
             }
             if (mine && cmd != cmdFirst) gfl |= RG_FLAG_STATE_MACHINE;
             recMax = i;
@@ -766,17 +842,19 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         }
         act = valid && !r.has(F_DEAD) && r.commit > r.applied;
       }
+      if (anyApply) storesPending = true;             // the record rows written above
     }
 
     STAMP(3);
     // ------------------------------------------------------------ 4. one leader per term, config.go:307-320
     {
-      const bool lead = valid && r.has(F_CONNECTED) && r.isLeader();
+      const bool lead = chkLeaders && valid && r.has(F_CONNECTED) && r.isLeader();
       const unsigned lm = G.ballot(lead);
+      chkLeaders = false;
       if (wave_any(lead && __popc(lm) > 1)) {
         SECTION_COUNT(w, 6);
 #pragma unroll
-        for (int u = 0; u < PP; u++) {
+        for (int u = 0; u < P; u++) {
           int tu = G.shfl(r.term, u);
           if (lead && u != peer && ((lm >> u) & 1u) && tu == r.term) gfl |= RG_FLAG_ELECTION_SAFETY;
         }
@@ -785,10 +863,11 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     STAMP(4);
   }
 
+#undef SYNC_STORES
 #undef nextRow
 #undef matchRow
 #undef rec
-  r.store(*Sp, gl);
+  if (G.inWave) r.store(*Sp, gl);
   gfl = G.gor(gfl);
   if (valid && peer == 0) {
     Sp->startSeq[g] = startSeq; Sp->partNext[g] = partNext; Sp->partEpoch[g] = partEpoch; Sp->recMax[g] = recMax;
@@ -1039,7 +1118,7 @@ __global__ __launch_bounds__(256) void k_hash(DevPtrs S, DevCfg c, u64 *out) {
 // ---------------------------------------------------------------- host side
 struct rg_engine {
   rg_config cfg;
-  int G, P, L, PP, Gpad, rowBytes, cmdOff;
+  int G, P, L, PP, Gpad, gpb, rowBytes, cmdOff;
   long long nLanes;
   DevPtrs S;
   DevPtrs *dS;          // device copy of S: the tick kernel reads the cold pointers through it
@@ -1202,8 +1281,8 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (!e) return RG_ERR_NOMEM;
   e->cfg = *cfg; e->G = cfg->n_groups; e->P = cfg->n_peers; e->L = cfg->log_cap;
   e->PP = e->P <= 4 ? 4 : 8;
-  const int gpb = 256 / e->PP;
-  e->Gpad = (e->G + gpb - 1) / gpb * gpb;
+  e->gpb = 4 * (64 / e->P);          // groups per block of the tick kernel: 64/P whole groups per wave
+  e->Gpad = (e->G + e->gpb - 1) / e->gpb * e->gpb;
   e->nLanes = (long long)e->Gpad * e->PP;
   e->cmdOff = (e->P * 4 + 7) & ~7;
   e->rowBytes = (e->cmdOff + e->P * 8 + 15) & ~15;
@@ -1295,10 +1374,18 @@ extern "C" int rg_step(rg_engine *e, int32_t n_ticks) {
   if (e->pendingEv.size() >= 512) { rc = collect_events(e); if (rc != RG_OK) return rc; }
   hipEvent_t a, b;
   HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-  const int blocks = (int)(e->nLanes / 256);
+  const int blocks = e->Gpad / e->gpb;
   HIPCHK(hipEventRecord(a, e->stream));
-  if (e->PP == 4) hipLaunchKernelGGL(k_tick<4>, dim3(blocks), dim3(256), 0, e->stream, (const DevPtrs *)e->dS, e->H, e->dc, (int)e->now, (int)n_ticks);
-  else hipLaunchKernelGGL(k_tick<8>, dim3(blocks), dim3(256), 0, e->stream, (const DevPtrs *)e->dS, e->H, e->dc, (int)e->now, (int)n_ticks);
+  const DevPtrs *dS = e->dS;
+  switch (e->P) {
+  case 2: hipLaunchKernelGGL(k_tick<2>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
+  case 3: hipLaunchKernelGGL(k_tick<3>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
+  case 4: hipLaunchKernelGGL(k_tick<4>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
+  case 5: hipLaunchKernelGGL(k_tick<5>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
+  case 6: hipLaunchKernelGGL(k_tick<6>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
+  case 7: hipLaunchKernelGGL(k_tick<7>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
+  default: hipLaunchKernelGGL(k_tick<8>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
+  }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b, e->stream));
   e->pendingEv.push_back(std::make_pair(a, b));
@@ -1818,7 +1905,7 @@ extern "C" int rg_state_hash(rg_engine *e, uint64_t *out, int64_t n) {
   TmpBuf tb;
   u64 *d = tb.get<u64>((size_t)e->G);
   if (!d) return RG_ERR_NOMEM;
-  const int blocks = (int)(e->nLanes / 256);
+  const int blocks = (int)((e->nLanes + 255) / 256);
   if (e->PP == 4) hipLaunchKernelGGL(k_hash<4>, dim3(blocks), dim3(256), 0, e->stream, e->S, e->dc, d);
   else hipLaunchKernelGGL(k_hash<8>, dim3(blocks), dim3(256), 0, e->stream, e->S, e->dc, d);
   HIPCHK(hipGetLastError());
