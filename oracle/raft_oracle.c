@@ -100,7 +100,7 @@ static inline uint64_t stream_hash(uint64_t key, uint64_t stream, uint32_t a, ui
 static int32_t next_random(group_t *g, int p) {
   peer_t *rf = &g->peer[p];
   uint64_t h = stream_hash(g->key, STREAM_ELECTION, (uint32_t)p, rf->rngCtr++);
-  return (int32_t)(h % RG_TIMEOUT_SPAN_MS) + RG_TIMEOUT_BASE_MS;
+  return (int32_t)((uint32_t)(h >> 32) % RG_TIMEOUT_SPAN_MS) + RG_TIMEOUT_BASE_MS;
 }
 
 /* time.Sleep never returns early and overshoots by scheduler slack: the
@@ -240,11 +240,13 @@ static int net_outcome(const ro_engine *e, const group_t *g, int s, int j, uint3
   const rg_config *cf = &e->cfg;
   if (cf->req_drop_permille == 0 && cf->reply_drop_permille == 0 && cf->reply_delay_permille == 0) { *cost = 0; return NET_OK; }
   uint64_t h = stream_hash(g->key, STREAM_NET, ((uint32_t)s << 8) | (uint32_t)j, seq);
-  int32_t d = (int32_t)((h >> 58) % RG_NET_DELAY_SPAN_MS);                                   /* :222 */
+  /* the delays of one round come from one hash, 8 bits per target */
+  uint64_t delays = stream_hash(g->key, STREAM_NET, 0xFFFF0000u | (uint32_t)s, seq);
+  int32_t d = (int32_t)((((delays >> (8 * j)) & 0xFF) * RG_NET_DELAY_SPAN_MS) >> 8);         /* :222, 0..26 */
   if ((int32_t)((h & 0xFFFFF) % 1000) < cf->req_drop_permille) return NET_LOST;              /* :226 */
   if (d >= RG_RPC_WAIT_MS) return NET_REPLY_LOST;                    /* handler runs, the sender has given up */
   if ((int32_t)(((h >> 20) & 0xFFFFF) % 1000) < cf->reply_drop_permille) return NET_REPLY_LOST;   /* :273 */
-  if ((int32_t)(((h >> 40) & 0x3FFFF) % 1000) < cf->reply_delay_permille) return NET_REPLY_LOST;  /* :276 */
+  if ((int32_t)(((h >> 40) & 0xFFFFF) % 1000) < cf->reply_delay_permille) return NET_REPLY_LOST;  /* :276 */
   *cost = d;
   return NET_OK;
 }

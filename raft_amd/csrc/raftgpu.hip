@@ -114,15 +114,26 @@ struct WaveCtr { unsigned c[RG_CTR_SLOTS]; };
 #define STAMP_INIT do { } while (0)
 #endif
 
-// Registers of one peer.
-struct Lane {
+enum { CD_SNAPTERM = 0, CD_SNAPVOTE, CD_SNAPLEN, CD_RNGCTR, CD_ROUNDSEQ, CD_AH_LO, CD_AH_HI, CD_N };
+
+typedef __attribute__((address_space(3))) int lds_int;
+
+// Registers of one peer.  CP = type of the pointer to the event-only words (LDS rows or a local array).
+template <typename CP>
+struct LaneT {
   int term, vote, commit, applied, logLen, timer, timeout, hbTimer, elNext, monNext;
-  int snapTerm, snapVote, snapLen, snapSync;
+  int snapSync;
   // caches of log words (rebuilt by k_derive after host writes): term of the last entry, first index from
   // which every entry carries the current term, term of the entry at commitIndex
   int lastTerm, firstOwn, cTerm;
-  unsigned flags, rngCtr, roundSeq;
-  u64 applyHash;
+  unsigned flags;
+  // Words touched only by events (persist, draws, round numbering, apply digest) live outside the register
+  // file: in the tick kernel in LDS, one 256-lane row per word (cs = 256), so any lane of the group can also read
+  // a peer's word directly; in the one-thread-per-command kernels in a local array (cs = 1).
+  CP cold; int cs;
+  __device__ auto &cd(int f) const { return cold[f * cs]; }
+  __device__ u64 applyHash() const { return ((u64)(unsigned)cd(CD_AH_HI) << 32) | (unsigned)cd(CD_AH_LO); }
+  __device__ void setApplyHash(u64 v) const { cd(CD_AH_LO) = (int)(unsigned)v; cd(CD_AH_HI) = (int)(unsigned)(v >> 32); }
 
   __device__ int state() const { return (int)(flags & F_STATE_MASK); }
   __device__ void setState(int s) { flags = (flags & ~F_STATE_MASK) | (unsigned)s; }
@@ -136,16 +147,16 @@ struct Lane {
   __device__ void load(const DevPtrs &S, long long gl) {
     term = S.term[gl]; vote = S.vote[gl]; flags = (unsigned)S.flags[gl]; commit = S.commit[gl]; applied = S.applied[gl];
     logLen = S.logLen[gl]; timer = S.timer[gl]; timeout = S.timeout[gl]; hbTimer = S.hbTimer[gl]; elNext = S.elNext[gl];
-    monNext = S.monNext[gl]; rngCtr = (unsigned)S.rngCtr[gl]; roundSeq = (unsigned)S.roundSeq[gl];
-    snapTerm = S.snapTerm[gl]; snapVote = S.snapVote[gl]; snapLen = S.snapLen[gl]; snapSync = S.snapSync[gl];
-    lastTerm = S.lastTerm[gl]; firstOwn = S.firstOwn[gl]; cTerm = S.commitTerm[gl]; applyHash = S.applyHash[gl];
+    monNext = S.monNext[gl]; cd(CD_RNGCTR) = S.rngCtr[gl]; cd(CD_ROUNDSEQ) = S.roundSeq[gl];
+    cd(CD_SNAPTERM) = S.snapTerm[gl]; cd(CD_SNAPVOTE) = S.snapVote[gl]; cd(CD_SNAPLEN) = S.snapLen[gl]; snapSync = S.snapSync[gl];
+    lastTerm = S.lastTerm[gl]; firstOwn = S.firstOwn[gl]; cTerm = S.commitTerm[gl]; setApplyHash(S.applyHash[gl]);
   }
   __device__ void store(const DevPtrs &S, long long gl) const {
     S.term[gl] = term; S.vote[gl] = vote; S.flags[gl] = (int)flags; S.commit[gl] = commit; S.applied[gl] = applied;
     S.logLen[gl] = logLen; S.timer[gl] = timer; S.timeout[gl] = timeout; S.hbTimer[gl] = hbTimer; S.elNext[gl] = elNext;
-    S.monNext[gl] = monNext; S.rngCtr[gl] = (int)rngCtr; S.roundSeq[gl] = (int)roundSeq;
-    S.snapTerm[gl] = snapTerm; S.snapVote[gl] = snapVote; S.snapLen[gl] = snapLen; S.snapSync[gl] = snapSync;
-    S.lastTerm[gl] = lastTerm; S.firstOwn[gl] = firstOwn; S.commitTerm[gl] = cTerm; S.applyHash[gl] = applyHash;
+    S.monNext[gl] = monNext; S.rngCtr[gl] = cd(CD_RNGCTR); S.roundSeq[gl] = cd(CD_ROUNDSEQ);
+    S.snapTerm[gl] = cd(CD_SNAPTERM); S.snapVote[gl] = cd(CD_SNAPVOTE); S.snapLen[gl] = cd(CD_SNAPLEN); S.snapSync[gl] = snapSync;
+    S.lastTerm[gl] = lastTerm; S.firstOwn[gl] = firstOwn; S.commitTerm[gl] = cTerm; S.applyHash[gl] = applyHash();
   }
 };
 
@@ -171,38 +182,43 @@ __device__ static inline void ctr_add(WaveCtr *w, int which, unsigned v) { atomi
 // shares the log rows and persist() moves no entry.  snapSync only keeps the count of entries a copying
 // implementation would have to write (RG_C_PERSIST_ENTRIES).  An imported blob (Persister swap) lives
 // in the separate snapshot rows until the next persist().
-__device__ static inline void persist(Lane &r, int L, WaveCtr *w) {
+template <class LN>
+__device__ static inline void persist(LN &r, int L, WaveCtr *w) {
   int n = r.commit + 1;
   if (n > L) n = L;
-  r.snapTerm = r.term;
-  r.snapVote = r.vote;
+  r.cd(CD_SNAPTERM) = r.term;
+  r.cd(CD_SNAPVOTE) = r.vote;
   if (n > r.snapSync) {
     ctr_add(w, RG_C_PERSIST_ENTRIES, (unsigned)(n - r.snapSync));
     r.snapSync = n;
   }
-  r.snapLen = n;
+  r.cd(CD_SNAPLEN) = n;
   r.flags = (r.flags | F_SNAPHAS) & ~F_SNAPEXT;
   ctr_add(w, RG_C_PERSISTS, 1);
 }
 
 // nextRandom(), raft.go:532-534, on the peer's seeded stream
-__device__ static inline int next_random(Lane &r, u64 key, int peer) {
-  u64 h = stream_hash(key, STREAM_ELECTION, (unsigned)peer, r.rngCtr++);
-  return (int)(h % (u64)RG_TIMEOUT_SPAN_MS) + RG_TIMEOUT_BASE_MS;
+template <class LN>
+__device__ static inline int next_random(LN &r, u64 key, int peer) {
+  const unsigned ctr = (unsigned)r.cd(CD_RNGCTR);
+  r.cd(CD_RNGCTR) = (int)(ctr + 1u);
+  u64 h = stream_hash(key, STREAM_ELECTION, (unsigned)peer, ctr);
+  return (int)((unsigned)(h >> 32) % (unsigned)RG_TIMEOUT_SPAN_MS) + RG_TIMEOUT_BASE_MS;
 }
 
 // Make() + readPersist() + the head of election(), raft.go:700-731,129-152,538-547.
 // The harness's start1 runs crash1 first (config.go:137), so the peer comes
 // back disconnected.
-__device__ static inline void make_peer(Lane &r, const Rows &lg, const Rows &sn, int col, int L, u64 key, int now, WaveCtr *w) {
+template <class LN>
+__device__ static inline void make_peer(LN &r, const Rows &lg, const Rows &sn, int col, int L, u64 key, int now, WaveCtr *w) {
   r.flags &= ~(F_DEAD | F_STATE_MASK | F_STOP | F_CNT_MASK | F_MONALIVE | F_FIRST | F_RESTART | F_CDIRTY);
   r.term = 0; r.vote = -1;
   *lg.termp(0, col) = 0; *lg.cmdp(0, col) = 0;
   r.logLen = 1; r.commit = 0; r.applied = 0; r.timer = now; r.hbTimer = now;
   r.lastTerm = 0; r.cTerm = 0;
-  if (r.has(F_SNAPHAS) && r.snapLen >= 1) {
-    r.term = r.snapTerm; r.vote = r.snapVote;
-    int n = r.snapLen;
+  if (r.has(F_SNAPHAS) && r.cd(CD_SNAPLEN) >= 1) {
+    r.term = r.cd(CD_SNAPTERM); r.vote = r.cd(CD_SNAPVOTE);
+    int n = r.cd(CD_SNAPLEN);
     if (r.has(F_SNAPEXT))
       for (int i = r.snapSync; i < n; i++) { *lg.termp(i, col) = *sn.termp(i, col); *lg.cmdp(i, col) = *sn.cmdp(i, col); }
     if (n > r.snapSync) r.snapSync = n;
@@ -221,7 +237,8 @@ __device__ static inline void make_peer(Lane &r, const Rows &lg, const Rows &sn,
 }
 
 // Start(), raft.go:344-364.  Returns the index or -1.
-__device__ static inline int start_cmd(Lane &r, const Rows &lg, const Rows &sn, int col, int L, u64 cmd, unsigned &gfl, WaveCtr *w) {
+template <class LN>
+__device__ static inline int start_cmd(LN &r, const Rows &lg, const Rows &sn, int col, int L, u64 cmd, unsigned &gfl, WaveCtr *w) {
   if (!r.isLeader()) return -1;
   if (r.logLen >= L) { gfl |= RG_FLAG_LOG_OVERFLOW; return -1; }
   int idx = r.logLen;
@@ -239,7 +256,8 @@ __device__ static inline int start_cmd(Lane &r, const Rows &lg, const Rows &sn, 
 // ---- tentative handler results ------------------------------------------------
 struct VoteDecision { int rTerm; bool touch, raise, grant; };
 // RequestVote(), raft.go:200-232, evaluated without side effects.
-__device__ static inline VoteDecision decide_vote(const Lane &r, int myLastTerm, int aTerm, int cand, int lli, int llt) {
+template <class LN>
+__device__ static inline VoteDecision decide_vote(const LN &r, int myLastTerm, int aTerm, int cand, int lli, int llt) {
   VoteDecision d;
   if (aTerm < r.term) { d.rTerm = r.term; d.touch = false; d.raise = false; d.grant = false; return d; }
   d.touch = true;
@@ -249,7 +267,8 @@ __device__ static inline VoteDecision decide_vote(const Lane &r, int myLastTerm,
   d.grant = (v == -1 || v == cand) && (llt > myLastTerm || (llt == myLastTerm && lli >= r.commit));
   return d;
 }
-__device__ static inline void commit_vote(Lane &r, const VoteDecision &d, int aTerm, int cand, int now,
+template <class LN>
+__device__ static inline void commit_vote(LN &r, const VoteDecision &d, int aTerm, int cand, int now,
                                           const Rows &lg, const Rows &sn, int col, int L, WaveCtr *w) {
   if (!d.touch) return;
   if (d.raise) { r.term = aTerm; r.vote = -1; persist(r, L, w); }
@@ -260,7 +279,8 @@ __device__ static inline void commit_vote(Lane &r, const VoteDecision &d, int aT
 struct AppendDecision { int rTerm, ct, ci; bool touch, match; };
 // AppendEntries(), raft.go:270-321, evaluated without side effects.
 // myPrevTerm is logs[PrevLogIndex].Term of the receiver (any value if out of range).
-__device__ static inline AppendDecision decide_append(const Lane &r, const Rows &lg, int col, int aTerm, int prev, int prevTerm, int myPrevTerm) {
+template <class LN>
+__device__ static inline AppendDecision decide_append(const LN &r, const Rows &lg, int col, int aTerm, int prev, int prevTerm, int myPrevTerm) {
   AppendDecision d; d.ct = 0; d.ci = 0; d.match = false;
   if (aTerm < r.term) { d.rTerm = r.term; d.touch = false; return d; }
   d.touch = true;
@@ -378,20 +398,32 @@ struct GrpN {
 __device__ static inline bool wave_any(bool p) { return __ballot(p) != 0ull; }
 __device__ static inline void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-// network outcome of one Call, labrpc.go:216-307: 0 lost, 1 handler ran / reply lost, 2 round trip.
-// cost = how long the sender is held: the 25 ms wait without a reply (raft.go:473,608), else the net's delay.
-__device__ static inline int net_outcome(const DevCfg &c, u64 key, bool reachable, int s, int j, unsigned seq, int &cost) {
-  cost = RG_RPC_WAIT_MS;
+// The unreliable net's delays of one round, 8 bits per target (labrpc.go:222): one hash per round, so the
+// sender can add up its waits without asking the targets.
+__device__ static inline u64 round_delays(const DevCfg &c, u64 key, int s, unsigned seq) {
+  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) return 0;
+  return stream_hash(key, STREAM_NET, 0xFFFF0000u | (unsigned)s, seq);
+}
+__device__ static inline int delay_of(u64 delays, int j) { return (int)((((unsigned)(delays >> (8 * j)) & 0xFFu) * (unsigned)RG_NET_DELAY_SPAN_MS) >> 8); }
+// network outcome of one Call, labrpc.go:216-307: 0 lost, 1 handler ran / reply lost, 2 round trip
+__device__ static inline int net_outcome(const DevCfg &c, u64 key, bool reachable, int s, int j, unsigned seq, u64 delays) {
   if (!reachable) return 0;
-  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) { cost = 0; return 2; }
+  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) return 2;
   u64 h = stream_hash(key, STREAM_NET, ((unsigned)s << 8) | (unsigned)j, seq);
-  int d = (int)((unsigned)(h >> 58) % (unsigned)RG_NET_DELAY_SPAN_MS);
   if ((int)((unsigned)(h & 0xFFFFF) % 1000u) < c.reqDrop) return 0;
-  if (d >= RG_RPC_WAIT_MS) return 1;
+  if (delay_of(delays, j) >= RG_RPC_WAIT_MS) return 1;          // the handler runs, the sender has given up
   if ((int)((unsigned)((h >> 20) & 0xFFFFF) % 1000u) < c.replyDrop) return 1;
-  if ((int)((unsigned)((h >> 40) & 0x3FFFF) % 1000u) < c.replyDelay) return 1;
-  cost = d;
+  if ((int)((unsigned)((h >> 40) & 0xFFFFF) % 1000u) < c.replyDelay) return 1;
   return 2;
+}
+// How long a round holds its sender: 25 ms for every Call without a reply (raft.go:473,608), else the net's delay.
+template <int P>
+__device__ static inline int round_busy(unsigned calledM, unsigned okM, u64 delays) {
+  int busy = 0;
+#pragma unroll
+  for (int j = 0; j < P; j++)
+    if ((calledM >> j) & 1u) busy += ((okM >> j) & 1u) ? delay_of(delays, j) : RG_RPC_WAIT_MS;
+  return busy;
 }
 
 // scheduler slack of the election loop's 50 ms sleep: 0..3 ms, seeded
@@ -444,9 +476,14 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #define rec(i) recBlk[rOff + (unsigned)(i)]
   const u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
-  Lane r;
+  __shared__ int coldLds[CD_N + 2][256];
+  LaneT<lds_int *> r;
+  r.cold = (lds_int *)&coldLds[0][threadIdx.x]; r.cs = 256;
   r.load(*Sp, gl);                       // tail lanes read a valid slot and never write it back
-  int startSeq = Sp->startSeq[gq], partNext = Sp->partNext[gq], partEpoch = Sp->partEpoch[gq], recMax = Sp->recMax[gq];
+#define gStartSeq coldLds[CD_N][threadIdx.x]
+#define gPartEpoch coldLds[CD_N + 1][threadIdx.x]
+  gStartSeq = Sp->startSeq[gq]; gPartEpoch = Sp->partEpoch[gq];
+  int partNext = Sp->partNext[gq], recMax = Sp->recMax[gq];
   unsigned gfl = 0;
   // next ticks of the periodic control events (kept as counters: no division in the loop)
   // Within a launch each lane caches the nextIndex / matchIndex words ONE leader (cOwner) keeps for it; memory is
@@ -467,17 +504,18 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     nextChurnTick = churnIt * c.churnPeriod;
   }
 
+  __builtin_amdgcn_s_waitcnt(0);         // nothing of the prologue is in flight when the loop starts
   for (int t = t0; t < t0 + nticks; t++) {
     const int now = t * RG_TICK_MS;
     STAMP_INIT;
     // ------------------------------------------------------------ 1. control
     if (c.partPeriod > 0 && wave_any(t == partNext)) chkLeaders = true;
     if (c.partPeriod > 0 && t == partNext) {
-      unsigned ep = (unsigned)partEpoch;
+      unsigned ep = (unsigned)gPartEpoch;
       r.set(F_SIDE, (stream_hash(key, STREAM_PART, ep, (unsigned)peer + 1) & 1) != 0);
       u64 h = stream_hash(key, STREAM_PART, ep, 0);
       partNext = t + c.partPeriod + (c.partJitter > 0 ? (int)(h % (u64)c.partJitter) : 0);
-      partEpoch++;
+      gPartEpoch++;
     }
     if (t == nextChurnTick) {                                        // test_test.go:893-919
       unsigned it = (unsigned)churnIt;
@@ -504,23 +542,23 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         unsigned mAll = G.ballot(cand), mRoom = G.ballot(room);
         unsigned below = (1u << peer) - 1u;
         if (c.startMode == RG_START_ALL) {
-          int seq = startSeq + __popc(mRoom & below);
+          int seq = gStartSeq + __popc(mRoom & below);
           bool tried = cand && seq < c.startMax;
           if (tried) {
             u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)seq);
             start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
           }
           int acc = __popc(mRoom);
-          int left = c.startMax - startSeq;
-          startSeq += acc < left ? acc : (left > 0 ? left : 0);
-        } else if (startSeq < c.startMax) {
+          int left = c.startMax - gStartSeq;
+          gStartSeq += acc < left ? acc : (left > 0 ? left : 0);
+        } else if (gStartSeq < c.startMax) {
           // peers without room are tried (and flagged) until one accepts
           int wIdx = mRoom ? (__ffs((int)mRoom) - 1) : NONE;
           if (cand && peer <= wIdx) {
-            u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)startSeq);
+            u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)gStartSeq);
             start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
           }
-          if (mRoom) startSeq++;
+          if (mRoom) gStartSeq++;
           (void)mAll;
         }
         storesPending = true;
@@ -534,11 +572,11 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       const bool elDue = live && r.elNext <= now;
       const bool monDue = live && r.has(F_MONALIVE) && r.monNext <= now;
       int start = 0, myPos = 0;
-      bool pend = false, specEl = false, specMon = false;
+      bool pend = false, specEl = false, specMon = false, pendLocal = false;
       if (elDue) {
         int st = r.state();
         if (st == RG_FOLLOWER) {
-          if (now - r.timer > r.timeout) pend = true;
+          if (now - r.timer > r.timeout) { pend = true; pendLocal = true; }
           else r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);   // nothing later in this tick can make it fire
         } else if (st == RG_CANDIDATE) pend = true;
         else specEl = true;
@@ -554,6 +592,18 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         }
       }
       if (pend) { specEl = false; specMon = false; }
+      // A timed-out follower only turns candidate (raft.go:557-562): no RPC.  When no peer of its group can run a
+      // round in this tick nothing can reach it before its turn, so it need not wait for it.
+      if (wave_any(pendLocal)) {
+        const bool grpRound = G.ballot(pend && !pendLocal) != 0;
+        if (pendLocal && !grpRound) {
+          r.setState(RG_CANDIDATE);
+          r.timeout = next_random(r, key, peer);
+          ctr_add(w, RG_C_TIMEOUTS, 1);
+          r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);
+          pend = false;
+        }
+      }
       STAMP(1);
       if (wave_any(pend)) { start = turn_start(key, t, P); myPos = peer - start + (peer < start ? P : 0); }
 
@@ -600,13 +650,13 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           }
           const bool inR = G.ballot(wantRV) != 0;
           const int T = G.shfl(r.term, sIdx), lli = G.shfl(aLli, sIdx), llt = G.shfl(aLlt, sIdx);
-          const unsigned seq = G.shflu(r.roundSeq, sIdx);
+          const unsigned seq = (unsigned)r.cold[CD_ROUNDSEQ * 256 + (sIdx - peer)];   // the sender's word, read in place
           const unsigned fS = G.shflu(r.flags, sIdx);
-          if (wantRV) r.roundSeq++;
+          if (wantRV) r.cd(CD_ROUNDSEQ) = (int)(seq + 1u);
           const bool tgt = inR && valid && peer != s;
           const bool reach = tgt && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
-          int cost = 0;
-          const int out = tgt ? net_outcome(c, key, reach, s, peer, seq, cost) : 0;
+          const u64 delays = round_delays(c, key, sIdx, seq);
+          const int out = tgt ? net_outcome(c, key, reach, s, peer, seq, delays) : 0;
           VoteDecision d; d.rTerm = 0; d.touch = d.raise = d.grant = false;
           if (out != 0) d = decide_vote(r, r.cTerm, T, s, lli, llt);
           const unsigned sdm = G.ballot(out == 2 && d.rTerm > T);      // raft.go:622
@@ -618,7 +668,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             if (wasLead && d.touch && myPos > sPos && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok), grantM = G.ballot(ok && d.grant);
-          const int busy = G.gsum(called ? cost : 0);
+          const int busy = round_busy<P>(calledM, okM, delays);
           bool won = false;
           if (wantRV) {
             ctr_add(w, RG_C_RPC_SENT, (unsigned)__popc(calledM));
@@ -648,7 +698,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             r.elNext = now + busy + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);
           }
           const bool grpWon = G.ballot(won) != 0;
-          const int lenW = G.shfl(r.logLen, sIdx);
+          int lenW = 0;
+          if (wave_any(won)) lenW = G.shfl(r.logLen, sIdx);
           if (grpWon && valid) { nextRow(sIdx * PP + peer) = lenW; matchRow(sIdx * PP + peer) = 0; cOwner = s; cNext = lenW; cMatch = 0; }
           if (wave_any(grpWon)) storesPending = true;
         }
@@ -708,9 +759,9 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           const bool inR = G.ballot(wantAE) != 0;
           const int T = G.shfl(r.term, sIdx), lenS = G.shfl(r.logLen, sIdx), commitS = G.shfl(r.commit, sIdx);
           const int lastTermS = G.shfl(r.lastTerm, sIdx), firstOwnS = G.shfl(r.firstOwn, sIdx), cTermS = G.shfl(r.cTerm, sIdx);
-          const unsigned seq = G.shflu(r.roundSeq, sIdx);
+          const unsigned seq = (unsigned)r.cold[CD_ROUNDSEQ * 256 + (sIdx - peer)];
           const unsigned fS = G.shflu(r.flags, sIdx);
-          if (wantAE) r.roundSeq++;
+          if (wantAE) r.cd(CD_ROUNDSEQ) = (int)(seq + 1u);
           const bool tgt = inR && valid && peer != s;
           if (wave_any(tgt && cOwner != s)) {
             SYNC_STORES();
@@ -722,8 +773,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           const int firstOv = ovm ? (__ffs((int)ovm) - 1) : NONE;
           const bool tgt2 = tgt && peer < firstOv;
           const bool reach = tgt2 && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
-          int cost = 0;
-          const int out = tgt2 ? net_outcome(c, key, reach, s, peer, seq, cost) : 0;
+          const u64 delays = round_delays(c, key, sIdx, seq);
+          const int out = tgt2 ? net_outcome(c, key, reach, s, peer, seq, delays) : 0;
           const int prev = nx - 1, k = lenS - nx;
           AppendDecision d; d.rTerm = 0; d.ct = 0; d.ci = 0; d.touch = d.match = false;
           int prevTerm = 0;
@@ -769,13 +820,14 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             nextRow(sIdx * PP + peer) = cNext;
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
-          const int busy = G.gsum(called ? cost : 0);
-          const int rTermB = G.shfl(d.rTerm, b < NONE ? b : 0);
+          const int busy = round_busy<P>(calledM, okM, delays);
+          int rTermB = 0;
+          if (wave_any(b < NONE)) rTermB = G.shfl(d.rTerm, b < NONE ? b : 0);
           if (wantAE) {
             ctr_add(w, RG_C_RPC_SENT, (unsigned)__popc(calledM));
             ctr_add(w, RG_C_RPC_DELIVERED, (unsigned)__popc(ranM));
-            ctr_add(w, RG_C_AE_DELIVERED, (unsigned)__popc(ranM));
             ctr_add(w, RG_C_RPC_REPLIED, (unsigned)__popc(okM));
+            ctr_add(w, RG_C_AE_DELIVERED, (unsigned)__popc(ranM));
             if (b < NONE) {                                            // raft.go:482-487: voteFor is kept
               r.setState(RG_FOLLOWER);
               r.term = rTermB;
@@ -809,22 +861,25 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       while (wave_any(act)) {
         SECTION_COUNT(w, 4);
         // lowest index any peer of the group applies now: nearly always the first pending lane's
-        const unsigned am = G.ballot(act);
-        int i = G.shfl(r.applied + 1, am ? (__ffs((int)am) - 1) : 0);
-        if (wave_any(act && r.applied + 1 < i)) i = G.gmin(act ? r.applied + 1 : 0x7fffffff);
-        const bool mine = act && r.applied + 1 == i;
-        const int ic = i < L ? i : L - 1;
+        // every pending lane fetches its own next entry and the record of that index right away, while
+        // the group settles which index is handled in this pass
+        const int mineIdx = r.applied + 1;
+        const int ic = mineIdx < L ? mineIdx : L - 1;
         u64 cmd = 0, seen = 0;
-        if (mine) {                                   // both loads in flight together
+        if (act) {
           cmd = *lg.cmdp(ic, peer);
-          if (i <= recMax) seen = rec(ic);
+          if (mineIdx <= recMax) seen = rec(ic);
         }
+        const unsigned am = G.ballot(act);
+        int i = G.shfl(mineIdx, am ? (__ffs((int)am) - 1) : 0);
+        if (wave_any(act && mineIdx < i)) i = G.gmin(act ? mineIdx : 0x7fffffff);
+        const bool mine = act && mineIdx == i;
         const unsigned mm = G.ballot(mine);
         const int first = mm ? (__ffs((int)mm) - 1) : 0;
         if (mine) {
           if (i >= r.logLen) gfl |= RG_FLAG_REF_PANIC;
           r.applied = i;
-          r.applyHash = sm64(r.applyHash ^ cmd ^ ((u64)(unsigned)i << 40));
+          r.setApplyHash(sm64(r.applyHash() ^ cmd ^ ((u64)(unsigned)i << 40)));
           ctr_add(w, RG_C_ENTRIES_APPLIED, 1);
         }
         const u64 cmdFirst = G.shfl64(cmd, first);
@@ -864,13 +919,16 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   }
 
 #undef SYNC_STORES
+  const int startSeqOut = gStartSeq, partEpochOut = gPartEpoch;
+#undef gStartSeq
+#undef gPartEpoch
 #undef nextRow
 #undef matchRow
 #undef rec
   if (G.inWave) r.store(*Sp, gl);
   gfl = G.gor(gfl);
   if (valid && peer == 0) {
-    Sp->startSeq[g] = startSeq; Sp->partNext[g] = partNext; Sp->partEpoch[g] = partEpoch; Sp->recMax[g] = recMax;
+    Sp->startSeq[g] = startSeqOut; Sp->partNext[g] = partNext; Sp->partEpoch[g] = partEpochOut; Sp->recMax[g] = recMax;
     if (gfl) Sp->gflags[g] |= gfl;
   }
   __syncthreads();
@@ -893,7 +951,8 @@ __global__ void k_host_cmds(DevPtrs S, DevCfg c, int PP, HostCmd *cmds, int n, i
     const long long gl = (long long)g * PP + p;
     const Rows lg = rows_of(S.logRows, c, g), sn = rows_of(S.snapRows, c, g);
     const u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
-    Lane r; r.load(S, gl);
+    int coldLocal[CD_N];
+    LaneT<int *> r; r.cold = coldLocal; r.cs = 1; r.load(S, gl);
     unsigned gfl = 0;
     switch (cm.op) {
     case OP_START: {
@@ -930,13 +989,14 @@ __global__ void k_rpc_vote(DevPtrs S, DevCfg c, int PP, const int *groups, const
     const int g = groups[i], p = peers[i];
     const long long gl = (long long)g * PP + p;
     const Rows lg = rows_of(S.logRows, c, g), sn = rows_of(S.snapRows, c, g);
-    Lane r; r.load(S, gl);
+    int coldLocal[CD_N];
+    LaneT<int *> r; r.cold = coldLocal; r.cs = 1; r.load(S, gl);
     if (!r.has(F_DEAD)) {
       rg_vote_args a = args[i];
       VoteDecision d = decide_vote(r, r.cTerm, a.term, a.candidate, a.last_log_index, a.last_log_term);
       commit_vote(r, d, a.term, a.candidate, now, lg, sn, p, c.L, &sctr);
       replies[i].term = d.rTerm; replies[i].granted = d.grant ? 1 : 0;
-      r.store(S, gl);
+        r.store(S, gl);
     }
   }
   __syncthreads();
@@ -955,7 +1015,8 @@ __global__ void k_rpc_append(DevPtrs S, DevCfg c, int PP, const int *groups, con
     const int g = groups[i], p = peers[i];
     const long long gl = (long long)g * PP + p;
     const Rows lg = rows_of(S.logRows, c, g), sn = rows_of(S.snapRows, c, g);
-    Lane r; r.load(S, gl);
+    int coldLocal[CD_N];
+    LaneT<int *> r; r.cold = coldLocal; r.cs = 1; r.load(S, gl);
     if (!r.has(F_DEAD)) {
       rg_append_args a = args[i];
       unsigned gfl = 0;
@@ -986,7 +1047,7 @@ __global__ void k_rpc_append(DevPtrs S, DevCfg c, int PP, const int *groups, con
         }
       }
       replies[i] = rep;
-      r.store(S, gl);
+        r.store(S, gl);
       if (gfl) atomicOr(&S.gflags[g], gfl);
     }
   }
@@ -1227,7 +1288,7 @@ static int init_state(rg_engine *e) {
       one[gl] = 1;
       if (p != 0) {                                              // raft.go:545-547
         u64 h = stream_hash(key, STREAM_ELECTION, (unsigned)p, 0);
-        timeout[gl] = (int)(h % (u64)RG_TIMEOUT_SPAN_MS) + RG_TIMEOUT_BASE_MS;
+        timeout[gl] = (int)((unsigned)(h >> 32) % (unsigned)RG_TIMEOUT_SPAN_MS) + RG_TIMEOUT_BASE_MS;
         rng[gl] = 1;
       }
     }
