@@ -469,7 +469,11 @@ static void apply_step(ro_engine *e, ctr_t *c, group_t *g, int p) {
     if (idx >= rf->logLen) g->flags |= RG_FLAG_REF_PANIC;
     if (idx >= e->L) idx = e->L - 1;
     uint64_t cmd = rf->logCmd[idx];
-    rf->applyHash = sm64(rf->applyHash ^ cmd ^ ((uint64_t)(uint32_t)rf->applied << 40));
+    {  /* apply digest: two independent 32-bit sums of a hash of (index, command), so that entries can be folded in any order */
+      uint64_t wd = sm64(cmd ^ ((uint64_t)(uint32_t)rf->applied << 40));
+      uint32_t lo = (uint32_t)rf->applyHash + (uint32_t)wd, hi = (uint32_t)(rf->applyHash >> 32) + (uint32_t)(wd >> 32);
+      rf->applyHash = ((uint64_t)hi << 32) | lo;
+    }
     if (rf->applied <= g->recMax) {
       if (g->applyRec[idx] != cmd) g->flags |= RG_FLAG_STATE_MACHINE;
     } else {

@@ -94,20 +94,33 @@ __host__ __device__ static inline u64 sm64(u64 x) {
 __host__ __device__ static inline u64 stream_hash(u64 key, u64 stream, unsigned a, unsigned b) {
   return sm64(key ^ (stream << 56) ^ ((u64)a << 32) ^ (u64)b);
 }
+// one applied entry's contribution to the peer's apply digest (a pair of 32-bit sums, so order-free)
+__host__ __device__ static inline u64 apply_word(u64 cmd, int idx) { return sm64(cmd ^ ((u64)(unsigned)idx << 40)); }
 __host__ __device__ static inline u64 elem_hash(unsigned peer, unsigned field, unsigned idx, u64 v) {
   return sm64(sm64(((u64)peer << 48) ^ ((u64)field << 32) ^ idx) ^ v);
 }
 
+// Loads and stores share the vmcnt counter on gfx950: a wait for a rarely taken load placed after the branches
+// merge would also drain every store in flight on the common path.  Rare loads therefore wait for their data
+// right where they are issued, inside their branch, and the common path never waits for memory.
+#define WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)   /* vmcnt(0) only */
+
+// All lanes that exchange data through global memory in the tick kernel sit in ONE wavefront (a group never spans
+// waves).  A wavefront's vector memory operations go through its CU's one vector L1 in issue order, so lanes of a
+// wave see each other's stores without waiting for them: the fence only has to stop the compiler from moving
+// accesses across it.
+__device__ static inline void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
 // per-wave counter block in LDS
-#define RG_CTR_SLOTS 32   // RG_N_COUNTERS public counters, then profiling slots (builds with -DRG_SECTION_COUNTS)
+#define RG_CTR_SLOTS 48   // RG_N_COUNTERS public counters, then profiling slots (builds with -DRG_SECTION_COUNTS)
 struct WaveCtr { unsigned c[RG_CTR_SLOTS]; };
 #ifdef RG_SECTION_COUNTS
 #define SECTION_COUNT(w, i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&(w)->c[RG_N_COUNTERS + (i)], 1u); } while (0)
 #else
 #define SECTION_COUNT(w, i) do { } while (0)
 #endif
-#ifdef RG_STAMPS   // diagnostic builds only: shader cycles per phase of a tick, summed per wave into slots 24..29
-#define STAMP(k) do { unsigned long long _n = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&w->c[24 + (k)], (unsigned)(_n - _stamp)); _stamp = _n; } while (0)
+#ifdef RG_STAMPS   // diagnostic builds only: shader cycles per phase of a tick, summed per wave into slots 32..
+#define STAMP(k) do { unsigned long long _n = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&w->c[32 + (k)], (unsigned)(_n - _stamp)); _stamp = _n; } while (0)
 #define STAMP_INIT unsigned long long _stamp = __builtin_readcyclecounter()
 #else
 #define STAMP(k) do { } while (0)
@@ -225,8 +238,9 @@ __device__ static inline void make_peer(LN &r, const Rows &lg, const Rows &sn, i
     r.logLen = n;
     persist(r, L, w);                     // raft.go:147 runs with commitIndex still 0
     r.commit = r.logLen - 1;              // raft.go:148
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    wave_fence();
     r.lastTerm = *lg.termp(r.logLen - 1, col);
+    WAIT_LOADS();
     r.cTerm = r.lastTerm;
   }
   r.monNext = 0;
@@ -396,8 +410,6 @@ struct GrpN {
 };
 
 __device__ static inline bool wave_any(bool p) { return __ballot(p) != 0ull; }
-__device__ static inline void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
-
 // The unreliable net's delays of one round, 8 bits per target (labrpc.go:222): one hash per round, so the
 // sender can add up its waits without asking the targets.
 __device__ static inline u64 round_delays(const DevCfg &c, u64 key, int s, unsigned seq) {
@@ -477,6 +489,20 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   const u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
   __shared__ int coldLds[CD_N + 2][256];
+  // The last RING entries each peer wrote to its log, and the last RING records of each group, staged in LDS:
+  // a follower copies a leader's fresh entries, and every peer applies its fresh entries, without a trip to
+  // HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
+  constexpr int RING = 4;
+  __shared__ int ringIdx[RING][256];
+  __shared__ int ringTerm[RING][256];
+  __shared__ u64 ringCmd[RING][256];
+  __shared__ int recIdx[RING][GPB];
+  __shared__ u64 recVal[RING][GPB];
+  const int tid = (int)threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < RING; q++) { ringIdx[q][tid] = -1; if (tid < GPB) recIdx[q][tid] = -1; }
+  __syncthreads();
+#define RING_PUSH(i_, tm_, cm_) do { const int _q = (i_) & (RING - 1); ringIdx[_q][tid] = (i_); ringTerm[_q][tid] = (tm_); ringCmd[_q][tid] = (cm_); } while (0)
   LaneT<lds_int *> r;
   r.cold = (lds_int *)&coldLds[0][threadIdx.x]; r.cs = 256;
   r.load(*Sp, gl);                       // tail lanes read a valid slot and never write it back
@@ -491,7 +517,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   int cOwner = -1, cNext = 0, cMatch = 0;
   // stores to words another lane may read later are drained (vmcnt) only right before such a read
   bool storesPending = false;
-#define SYNC_STORES() do { if (storesPending) { wg_fence(); storesPending = false; } } while (0)
+#define SYNC_STORES() do { if (storesPending) { SECTION_COUNT(w, 7); wave_fence(); storesPending = false; } } while (0)
   bool chkLeaders = true;      // the one-leader check is re-evaluated only after something changed
   int nextStartTick = 0x7fffffff, nextChurnTick = 0x7fffffff, churnIt = 0;
   if (c.startPeriod > 0) {
@@ -524,7 +550,11 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       u64 h1 = stream_hash(key, STREAM_CHURN, it, 0), h2 = stream_hash(key, STREAM_CHURN, it, 1), h3 = stream_hash(key, STREAM_CHURN, it, 2);
       if ((int)((unsigned)(h1 & 0xFFFFF) % 1000u) < c.churnDisc && peer == (int)((h1 >> 32) % (u64)P)) r.flags &= ~F_CONNECTED;
       if ((int)((unsigned)(h2 & 0xFFFFF) % 1000u) < c.churnRestart && valid && peer == (int)((h2 >> 32) % (u64)P)) {
-        if (r.has(F_DEAD)) make_peer(r, lg, sn, peer, L, key, now, w);
+        if (r.has(F_DEAD)) {
+          make_peer(r, lg, sn, peer, L, key, now, w);
+#pragma unroll
+          for (int q = 0; q < RING; q++) ringIdx[q][tid] = -1;     // the log may have been rebuilt from an imported blob
+        }
         r.flags |= F_CONNECTED;
       }
       if ((int)((unsigned)(h3 & 0xFFFFF) % 1000u) < c.churnCrash && peer == (int)((h3 >> 32) % (u64)P) && !r.has(F_DEAD)) {
@@ -546,7 +576,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           bool tried = cand && seq < c.startMax;
           if (tried) {
             u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)seq);
-            start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
+            const int at = start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
+            if (at >= 0) RING_PUSH(at, r.term, cmd);
           }
           int acc = __popc(mRoom);
           int left = c.startMax - gStartSeq;
@@ -556,7 +587,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           int wIdx = mRoom ? (__ffs((int)mRoom) - 1) : NONE;
           if (cand && peer <= wIdx) {
             u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)gStartSeq);
-            start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
+            const int at = start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
+            if (at >= 0) RING_PUSH(at, r.term, cmd);
           }
           if (mRoom) gStartSeq++;
           (void)mAll;
@@ -633,6 +665,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             r.elNext = now + RG_ELECTION_PERIOD_MS + RG_ELECTION_LEADER_EXTRA_MS + sleep_slack(key, peer, now);
           }
         }
+        STAMP(5);
         if (wave_any(wantRV)) {
           SECTION_COUNT(w, 1);
           // candidate prologue, raft.go:566-590
@@ -703,6 +736,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           if (grpWon && valid) { nextRow(sIdx * PP + peer) = lenW; matchRow(sIdx * PP + peer) = 0; cOwner = s; cNext = lenW; cMatch = 0; }
           if (wave_any(grpWon)) storesPending = true;
         }
+        STAMP(6);
         // ---------------- leader loop, raft.go:395-529, until it sleeps or exits
         bool monAct = isS && r.has(F_MONALIVE) && r.monNext <= now;
         for (;;) {
@@ -718,7 +752,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             const bool fol = G.ballot(needCR) != 0 && valid && peer != s;
             if (wave_any(fol && cOwner != s)) {
               SYNC_STORES();
-              if (fol && cOwner != s) { cNext = nextRow(sIdx * PP + peer); cMatch = matchRow(sIdx * PP + peer); cOwner = s; }
+              if (fol && cOwner != s) { cNext = nextRow(sIdx * PP + peer); cMatch = matchRow(sIdx * PP + peer); cOwner = s; WAIT_LOADS(); }
             }
             const int mv = fol ? cMatch : -1;
             int ge = 0;
@@ -753,6 +787,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             }
           }
           SECTION_COUNT(w, 2);
+          STAMP(7);
           if (!wave_any(wantAE)) break;
           SECTION_COUNT(w, 3);
           // ---------------- one replication round, raft.go:423-512
@@ -764,10 +799,10 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           if (wantAE) r.cd(CD_ROUNDSEQ) = (int)(seq + 1u);
           const bool tgt = inR && valid && peer != s;
           if (wave_any(tgt && cOwner != s)) {
+            SECTION_COUNT(w, 8);
             SYNC_STORES();
-            if (tgt && cOwner != s) { cNext = nextRow(sIdx * PP + peer); cMatch = matchRow(sIdx * PP + peer); cOwner = s; }
+            if (tgt && cOwner != s) { cNext = nextRow(sIdx * PP + peer); cMatch = matchRow(sIdx * PP + peer); cOwner = s; WAIT_LOADS(); }
           }
-          if (wave_any(tgt)) SYNC_STORES();                        // the round reads the sender's log rows
           const int nx = tgt ? cNext : 0;
           const unsigned ovm = G.ballot(tgt && nx > lenS);           // raft.go:451-454 ends the round
           const int firstOv = ovm ? (__ffs((int)ovm) - 1) : NONE;
@@ -778,15 +813,62 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           const int prev = nx - 1, k = lenS - nx;
           AppendDecision d; d.rTerm = 0; d.ct = 0; d.ci = 0; d.touch = d.match = false;
           int prevTerm = 0;
+          const int sTid = tid - peer + sIdx;                        // the sender's lane in the block
+          // logs[Prev].Term on both sides: from the lanes' caches, else from the rings, else from HBM
+          int myPrevTerm = -2;
+          bool needS = false, needM = false;
           if (out != 0) {
-            // logs[Prev].Term on both sides, from the caches where they cover it
-            prevTerm = prev == lenS - 1 ? lastTermS : (prev >= firstOwnS ? T : *lg.termp(prev, sIdx));
-            int myPrevTerm = prev == r.logLen - 1 ? r.lastTerm : (prev < r.logLen ? *lg.termp(prev, peer) : -2);
-            d = decide_append(r, lg, peer, T, prev, prevTerm, myPrevTerm);
+            prevTerm = prev == lenS - 1 ? lastTermS : T;
+            needS = prev != lenS - 1 && prev < firstOwnS;
+            if (prev == r.logLen - 1) myPrevTerm = r.lastTerm; else needM = prev < r.logLen - 1;
+            const int pq = prev & (RING - 1);
+            if (needS && ringIdx[pq][sTid] == prev) { prevTerm = ringTerm[pq][sTid]; needS = false; }
+            if (needM && ringIdx[pq][tid] == prev) { myPrevTerm = ringTerm[pq][tid]; needM = false; }
           }
+          if (wave_any(needS || needM)) {
+            SECTION_COUNT(w, 9);
+            SYNC_STORES();
+            if (needS || needM) {
+              if (needS) prevTerm = *lg.termp(prev, sIdx);
+              if (needM) myPrevTerm = *lg.termp(prev, peer);
+              WAIT_LOADS();
+            }
+          }
+          if (out != 0) d = decide_append(r, lg, peer, T, prev, prevTerm, myPrevTerm);
           const unsigned sdm = G.ballot(out == 2 && d.rTerm > T);    // raft.go:482
           const int b = sdm ? (__ffs((int)sdm) - 1) : NONE;
           const bool called = tgt2 && peer <= b, ran = out != 0 && peer <= b, ok = out == 2 && peer <= b;
+          // Entries the sender wrote recently are copied from its ring.  A longer or older run (a follower catching
+          // up) is copied by the whole wave, one row per lane, so that its cost is one trip to HBM whatever its length.
+          bool viaHbm = false;
+          if (ran && d.touch && d.match && k > 0) {
+            viaHbm = k > RING;
+#pragma unroll
+            for (int j = 0; j < RING; j++) if (j < k && ringIdx[(nx + j) & (RING - 1)][sTid] != nx + j) viaHbm = true;
+          }
+          {
+            u64 hm = __ballot(viaHbm);
+            const bool scan = ok && b != peer && d.touch && !d.match;
+            if (hm) SECTION_COUNT(w, 10);
+            if (wave_any(scan)) SECTION_COUNT(w, 11);
+            if (hm || wave_any(scan)) SYNC_STORES();
+            while (hm) {
+              const int src = (int)__builtin_ctzll(hm);
+              hm &= hm - 1;
+              const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src);
+              const int nxB = __builtin_amdgcn_readlane(nx, src), lenB = __builtin_amdgcn_readlane(lenS, src);
+              const unsigned sCol = (unsigned)__builtin_amdgcn_readlane(sIdx, src), tCol = (unsigned)__builtin_amdgcn_readlane(peer, src);
+              const int tTid = (tid & ~63) + src;
+              for (int i = nxB + G.lane; i < lenB; i += 64) {
+                char *row = lg.base + (size_t)(offB + (unsigned)i * (unsigned)lg.rowBytes);
+                const int tm = *(int *)(row + sCol * 4u);
+                const u64 cm = *(u64 *)(row + (unsigned)lg.cmdOff + sCol * 8u);
+                *(int *)(row + tCol * 4u) = tm;
+                *(u64 *)(row + (unsigned)lg.cmdOff + tCol * 8u) = cm;
+                if (i >= lenB - RING) { const int q = i & (RING - 1); ringIdx[q][tTid] = i; ringTerm[q][tTid] = tm; ringCmd[q][tTid] = cm; }
+              }
+            }
+          }
           if (ran && d.touch) {
             const bool wasLead = r.state() == RG_LEADER;
             r.setState(RG_FOLLOWER);
@@ -794,7 +876,14 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             if (r.term < T) { r.term = T; persist(r, L, w); }
             r.timer = now;
             if (d.match) {
-              for (int i = nx; i < lenS; i++) { *lg.termp(i, peer) = *lg.termp(i, sIdx); *lg.cmdp(i, peer) = *lg.cmdp(i, sIdx); }
+              if (!viaHbm) {
+                for (int i = nx; i < lenS; i++) {                    // at most RING entries, all in the sender's ring
+                  const int q = i & (RING - 1);
+                  const int tm = ringTerm[q][sTid]; const u64 cm = ringCmd[q][sTid];
+                  *lg.termp(i, peer) = tm; *lg.cmdp(i, peer) = cm;
+                  RING_PUSH(i, tm, cm);
+                }
+              }
               if (k > 0 && nx < r.snapSync) r.snapSync = nx;
               r.logLen = lenS;
               r.lastTerm = k > 0 ? lastTermS : prevTerm;
@@ -804,7 +893,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               if (r.commit != oldCommit || nx <= r.commit) {          // the entry at commitIndex is new or was rewritten
                 if (r.commit == lenS - 1) r.cTerm = r.lastTerm;
                 else if (r.commit == commitS && commitS < lenS) r.cTerm = cTermS;
-                else { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); r.cTerm = *lg.termp(r.commit < L ? r.commit : L - 1, peer); }
+                else { wave_fence(); r.cTerm = *lg.termp(r.commit < L ? r.commit : L - 1, peer); WAIT_LOADS(); }
               }
               persist(r, L, w);
               ctr_add(w, RG_C_ENTRIES_REPLICATED, (unsigned)k);
@@ -845,6 +934,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             if (busy > 0) { r.monNext = now + busy; monAct = false; }   // the loop goes on once the waits are over
           }
           storesPending = true;
+          STAMP(8);
         }
         if (isS) pend = false;
       }
@@ -854,50 +944,123 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 
     STAMP(2);
     // ------------------------------------------------------------ 3. apply, raft.go:676-686 + config.go:170-194
+    // The reference's tester sees peers 0..P-1 deliver in turn: peer p checks its entries up to the newest index
+    // recorded before its turn (pm = the larger of the record's end and the commitIndex of every lower peer)
+    // against the record, and records the rest.  Ranges of different peers that are recorded never overlap and the
+    // digest is a sum, so all peers record first and then all peers check, each range in one go.
     {
-      bool act = valid && !r.has(F_DEAD) && r.commit > r.applied;
-      const bool anyApply = wave_any(act);
-      if (anyApply) SYNC_STORES();
-      while (wave_any(act)) {
+      const bool act = valid && !r.has(F_DEAD) && r.commit > r.applied;
+      if (wave_any(act)) {
         SECTION_COUNT(w, 4);
-        // lowest index any peer of the group applies now: nearly always the first pending lane's
-        // every pending lane fetches its own next entry and the record of that index right away, while
-        // the group settles which index is handled in this pass
-        const int mineIdx = r.applied + 1;
-        const int ic = mineIdx < L ? mineIdx : L - 1;
-        u64 cmd = 0, seen = 0;
-        if (act) {
-          cmd = *lg.cmdp(ic, peer);
-          if (mineIdx <= recMax) seen = rec(ic);
-        }
-        const unsigned am = G.ballot(act);
-        int i = G.shfl(mineIdx, am ? (__ffs((int)am) - 1) : 0);
-        if (wave_any(act && mineIdx < i)) i = G.gmin(act ? mineIdx : 0x7fffffff);
-        const bool mine = act && mineIdx == i;
-        const unsigned mm = G.ballot(mine);
-        const int first = mm ? (__ffs((int)mm) - 1) : 0;
-        if (mine) {
-          if (i >= r.logLen) gfl |= RG_FLAG_REF_PANIC;
-          r.applied = i;
-          r.setApplyHash(sm64(r.applyHash() ^ cmd ^ ((u64)(unsigned)i << 40)));
-          ctr_add(w, RG_C_ENTRIES_APPLIED, 1);
-        }
-        const u64 cmdFirst = G.shfl64(cmd, first);
-        if (mm) {
-          if (i <= recMax) {
-            if (mine && seen != cmd) gfl |= RG_FLAG_STATE_MACHINE;
-          } else {
-            if (mine && peer == first) {
-              if (i != recMax + 1) gfl |= RG_FLAG_APPLY_ORDER;
-              rec(ic) = cmd;
-            }
-            if (mine && cmd != cmdFirst) gfl |= RG_FLAG_STATE_MACHINE;
-            recMax = i;
+        const int cA = act ? r.commit : 0;
+        int pm = recMax, newMax = recMax;
+        if (wave_any(cA > recMax)) {
+#pragma unroll
+          for (int u = 0; u < P; u++) {
+            const int v = G.shfl(cA, u);
+            if (u < peer) pm = v > pm ? v : pm;
+            newMax = v > newMax ? v : newMax;
           }
         }
-        act = valid && !r.has(F_DEAD) && r.commit > r.applied;
+        const int cmpHi = cA < pm ? cA : pm;
+        const int nCmp = (act && cmpHi > r.applied) ? cmpHi - r.applied : 0;       // checks (applied, cmpHi]
+        const int recLo = r.applied > pm ? r.applied : pm;
+        const int nRec = (act && r.commit > recLo) ? r.commit - recLo : 0;         // records (recLo, commit]
+        if (nRec > 0 && r.applied > pm) gfl |= RG_FLAG_APPLY_ORDER;                // config.go:184-187
+        if (act && r.commit >= r.logLen) gfl |= RG_FLAG_REF_PANIC;                 // raft.go:679 would index past the log
+        unsigned accLo = 0, accHi = 0;
+        bool bad = false;
+        // ---- record
+        if (wave_any(nRec > 0)) {
+          bool slow = nRec > RING;
+#pragma unroll
+          for (int j = 0; j < RING; j++) if (j < nRec && ringIdx[(recLo + 1 + j) & (RING - 1)][tid] != recLo + 1 + j) slow = true;
+          u64 sm = __ballot(slow);
+          if (nRec > 0 && !slow) {
+            for (int j = 0; j < nRec; j++) {
+              const int i = recLo + 1 + j, q = i & (RING - 1);
+              const u64 cmd = ringCmd[q][tid];
+              rec(i < L ? i : L - 1) = cmd;
+              if (i > newMax - RING) { recIdx[q][gLoc] = i; recVal[q][gLoc] = cmd; }
+              const u64 wd = apply_word(cmd, i);
+              accLo += (unsigned)wd; accHi += (unsigned)(wd >> 32);
+            }
+          }
+          if (sm) {                                   // long or old runs: the whole wave, one entry per lane
+            SECTION_COUNT(w, 13);
+            SYNC_STORES();
+            do {
+              const int src = (int)__builtin_ctzll(sm);
+              sm &= sm - 1;
+              const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), rOffB = (unsigned)__builtin_amdgcn_readlane((int)rOff, src);
+              const int lo = __builtin_amdgcn_readlane(recLo, src), n = __builtin_amdgcn_readlane(nRec, src);
+              const int top = __builtin_amdgcn_readlane(newMax, src), gSrc = __builtin_amdgcn_readlane((int)gLoc, src);
+              const unsigned col = (unsigned)__builtin_amdgcn_readlane(peer, src);
+              const int tTid = (tid & ~63) + src;
+              for (int j = G.lane; j < n; j += 64) {
+                const int i = lo + 1 + j, ic = i < L ? i : L - 1, q = i & (RING - 1);
+                const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
+                recBlk[rOffB + (unsigned)ic] = cmd;
+                if (i > top - RING) { recIdx[q][gSrc] = i; recVal[q][gSrc] = cmd; }
+                const u64 wd = apply_word(cmd, i);
+                atomicAdd((unsigned *)&coldLds[CD_AH_LO][tTid], (unsigned)wd);
+                atomicAdd((unsigned *)&coldLds[CD_AH_HI][tTid], (unsigned)(wd >> 32));
+              }
+            } while (sm);
+          }
+          recMax = newMax;
+          storesPending = true;
+        }
+        // ---- check
+        if (wave_any(nCmp > 0)) {
+          bool slow = nCmp > RING;
+#pragma unroll
+          for (int j = 0; j < RING; j++) {
+            const int i = r.applied + 1 + j, q = i & (RING - 1);
+            if (j < nCmp && !(ringIdx[q][tid] == i && recIdx[q][gLoc] == i)) slow = true;
+          }
+          u64 sm = __ballot(slow);
+          if (nCmp > 0 && !slow) {
+            for (int j = 0; j < nCmp; j++) {
+              const int i = r.applied + 1 + j, q = i & (RING - 1);
+              const u64 cmd = ringCmd[q][tid];
+              bad |= cmd != recVal[q][gLoc];
+              const u64 wd = apply_word(cmd, i);
+              accLo += (unsigned)wd; accHi += (unsigned)(wd >> 32);
+            }
+          }
+          if (sm) {
+            SECTION_COUNT(w, 12);
+            SYNC_STORES();
+            do {
+              const int src = (int)__builtin_ctzll(sm);
+              sm &= sm - 1;
+              const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), rOffB = (unsigned)__builtin_amdgcn_readlane((int)rOff, src);
+              const int a = __builtin_amdgcn_readlane(r.applied, src), n = __builtin_amdgcn_readlane(nCmp, src);
+              const unsigned col = (unsigned)__builtin_amdgcn_readlane(peer, src);
+              const int tTid = (tid & ~63) + src;
+              bool differs = false;
+              for (int j = G.lane; j < n; j += 64) {
+                const int i = a + 1 + j, ic = i < L ? i : L - 1;
+                const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
+                const u64 seen = recBlk[rOffB + (unsigned)ic];
+                differs |= cmd != seen;
+                const u64 wd = apply_word(cmd, i);
+                atomicAdd((unsigned *)&coldLds[CD_AH_LO][tTid], (unsigned)wd);
+                atomicAdd((unsigned *)&coldLds[CD_AH_HI][tTid], (unsigned)(wd >> 32));
+              }
+              if (wave_any(differs) && G.lane == src) bad = true;
+            } while (sm);
+          }
+        }
+        if (act) {
+          if (bad) gfl |= RG_FLAG_STATE_MACHINE;
+          ctr_add(w, RG_C_ENTRIES_APPLIED, (unsigned)(r.commit - r.applied));
+          r.applied = r.commit;
+          atomicAdd((unsigned *)&coldLds[CD_AH_LO][tid], accLo);
+          atomicAdd((unsigned *)&coldLds[CD_AH_HI][tid], accHi);
+        }
       }
-      if (anyApply) storesPending = true;             // the record rows written above
     }
 
     STAMP(3);
@@ -919,6 +1082,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   }
 
 #undef SYNC_STORES
+#undef RING_PUSH
   const int startSeqOut = gStartSeq, partEpochOut = gPartEpoch;
 #undef gStartSeq
 #undef gPartEpoch
