@@ -1,0 +1,102 @@
+"""The named benchmark configurations, HIP engine vs CPU oracle (-m gpu).
+
+Reduced group counts run the whole schedule on both sides and compare per-group digests of every
+Raft-visible word, counters and flags.  The full-size runs compare a sample of shards: all seeded
+streams key on the global group id, so the oracle can replay any slice of the groups by itself."""
+import numpy as np
+import pytest
+
+from raft_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+CFG2 = dict(n_peers=5, log_cap=1024, seed=1, start_period=5, start_max=1000)
+CFG3 = dict(n_peers=5, log_cap=1024, seed=2, req_drop_permille=100, reply_drop_permille=100, start_period=5,
+            start_max=1000, part_period=100, part_jitter=20)
+# crash / restart through the snapshots every 70 ticks (test_test.go:893-919), every leader takes the Starts
+# (test_test.go:697-703) so that deposed leaders pile up entries that are truncated later (test_test.go:387-389)
+CFG4 = dict(n_peers=7, log_cap=4096, seed=4, req_drop_permille=50, reply_drop_permille=50, start_period=10, start_max=3500,
+            start_mode=_abi.START_ALL, churn_period=70, churn_disconnect_permille=200, churn_restart_permille=500,
+            churn_crash_permille=200)
+CFG5 = dict(n_peers=3, log_cap=256, seed=5, req_drop_permille=10, reply_drop_permille=10, start_period=5, start_max=200)
+
+
+def _oracle(**kw):
+    from oracle.binding import OracleEngine
+    return OracleEngine(_abi.make_config(**kw))
+
+
+def _engine(**kw):
+    from raft_amd import Engine
+    return Engine(_abi.make_config(**kw))
+
+
+def _same(o, e):
+    assert np.array_equal(o.state_hash(), e.state_hash())
+    assert o.counters() == e.counters()
+    assert np.array_equal(o.read("gflags"), e.read("gflags"))
+    assert o.safety_check() == e.safety_check()
+
+
+@pytest.mark.parametrize("name,kw,groups,ticks", [
+    ("cfg2", CFG2, 4096, 10000),
+    ("cfg3", CFG3, 3000, 20000),
+    ("cfg4", CFG4, 300, 40000),
+    ("cfg5", CFG5, 8192, 4000),
+])
+def test_whole_schedule_reduced(name, kw, groups, ticks):
+    o, e = _oracle(n_groups=groups, **kw), _engine(n_groups=groups, **kw)
+    half = ticks // 2
+    for n in (half, ticks - half):
+        o.step_mt(n, 8)
+        e.step(n)
+        _same(o, e)
+    c = e.counters()
+    assert c["group_ticks"] == groups * ticks
+    assert c["entries_committed"] > 0
+    if name == "cfg2":
+        assert c["entries_committed"] == groups * 1000 and e.safety_flags() == (0, 0)
+    if name == "cfg4":
+        assert c["ae_conflicts"] > 0 and c["persist_entries"] > 0
+
+
+def _sampled_shards(kw, groups, ticks, shards, width, engine_base=0):
+    e = _engine(n_groups=groups, group_base=engine_base, **kw)
+    e.step(ticks)
+    h = e.state_hash()
+    fl = e.read("gflags")
+    for first in shards:
+        o = _oracle(n_groups=width, group_base=engine_base + first, **kw)
+        o.step_mt(ticks, 8)
+        assert np.array_equal(o.state_hash(), h[first:first + width]), "shard at group %d" % first
+        assert np.array_equal(o.read("gflags"), fl[first:first + width])
+    return e
+
+
+def test_cfg3_full_size_sampled_shards():
+    """65,536 five-peer groups, 10 % + 10 % loss, rolling partitions, 20,000 ticks in one launch."""
+    e = _sampled_shards(CFG3, 65536, 20000, (0, 21845, 40000, 65536 - 96), 96)
+    c = e.counters()
+    assert c["group_ticks"] == 65536 * 20000
+    # properties that need no oracle, on the groups in which the reference's code stays inside its own invariants
+    # (no flag raised): every live peer has applied all it knows committed, commitIndex is inside the log, all
+    # peers that applied the same number of entries hold the same apply digest
+    assert c["entries_committed"] <= c["entries_started"]
+    ok = e.read("gflags") == 0
+    commit, applied, loglen = e.read("commit")[ok], e.read("applied")[ok], e.read("loglen")[ok]
+    assert ok.sum() > 30000 and (applied == commit).all() and (commit < loglen).all()
+    digest = e.read("applyhash")[ok]
+    same = applied == applied[:, :1]
+    assert (digest[same] == np.broadcast_to(digest[:, :1], digest.shape)[same]).all()
+
+
+def test_cfg5_shard_of_a_million_groups():
+    """One rank's 131,072 three-peer groups of the 1,048,576-group job (rank 5 of 8): the result of a
+    shard depends only on its global group ids."""
+    _sampled_shards(CFG5, 131072, 4000, (0, 70000, 131072 - 128), 128, engine_base=5 * 131072)
+
+
+def test_cfg4_full_size_sampled_shards():
+    """16,384 seven-peer groups, 4096-entry logs, crash / restart churn."""
+    e = _sampled_shards(CFG4, 16384, 40000, (0, 9000, 16384 - 32), 32)
+    assert e.counters()["ae_conflicts"] > 0
