@@ -162,7 +162,7 @@ def main():
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and launch == 20000 and args.groups == 65536:   # the counters were collected on the default launch only
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
@@ -184,7 +184,8 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "kernel": "k_tick", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-            "mode": "fused: peer scalars stay in registers across the %d ticks of a launch" % launch,
+            "mode": ("fused: peer scalars stay in registers across the %d ticks of a launch" % launch) if launch > 1
+                    else "streamed: every peer's state is loaded and stored once per tick",
         },
         "safety_flags": flags, "flagged_groups": flagged_groups,
         "counters_per_step": counters,
