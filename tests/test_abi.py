@@ -29,6 +29,16 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_checker_header_and_loader_agree():
+    from raft_amd import lincheck
+    text = open(os.path.join(ROOT, "include", "lincheck.h")).read()
+    declared = sorted(set(re.findall(r"\b(lc_[a-z_0-9]+)\s*\(", text)))
+    assert declared == sorted(lincheck.EXPORTS)
+    lib = ctypes.CDLL(lincheck.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
 def test_version_and_strerror_without_gpu():
     lib = _abi.load_library()
     assert b"gfx950" in lib.rg_version()
