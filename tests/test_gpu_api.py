@@ -191,3 +191,13 @@ def test_state_digest_at_scale():
     commit = e.read("commit")
     assert (commit == 1000).all()
     assert (e.read("applyhash") == e.read("applyhash")[:, :1]).all()
+
+
+def test_abi_from_plain_c():
+    """tests/c/abi_smoke.c: the reference's first agreement test through the C ABI, no Python in between."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c", "abi_smoke")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
