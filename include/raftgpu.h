@@ -90,6 +90,8 @@ enum {
   RG_C_AE_CONFLICTS,        /* AppendEntries answered with a conflict hint (raft.go:303) */
   RG_C_STEPDOWNS,           /* sender saw a higher term in a reply (raft.go:482,622)     */
   RG_C_AE_DELIVERED,        /* AppendEntries handler runs (subset of RPC_DELIVERED)      */
+  RG_C_RPC_FIXED_BYTES,     /* fixed-width bytes on the wire: arguments of every Call + every reply the net carried, late ones included (labrpc.go:153-154,286-290) */
+  RG_C_AE_ENTRIES_SENT,     /* log entries carried by AppendEntries Calls                */
   RG_N_COUNTERS
 };
 
@@ -144,7 +146,9 @@ typedef struct rg_config {
   int32_t  churn_disconnect_permille;
   int32_t  churn_restart_permille;
   int32_t  churn_crash_permille;
-  int32_t  reserved[3];
+  /* wire-byte accounting for rg_rpc_bytes (RG_C_RPC_FIXED_BYTES, RG_C_AE_ENTRIES_SENT): off by default */
+  int32_t  account_bytes;
+  int32_t  reserved[2];
 } rg_config;
 
 typedef struct rg_engine rg_engine;
@@ -239,6 +243,15 @@ int rg_write_state(rg_engine *e, int32_t field, const void *src, int64_t src_byt
 int rg_state_hash(rg_engine *e, uint64_t *out, int64_t n_groups);
 
 int rg_counters(rg_engine *e, uint64_t *out /* RG_N_COUNTERS */);
+/* cfg.bytesTotal(), config.go:292-294 = labrpc's GetTotalBytes (labrpc.go:153-154,286-290): bytes of the
+ * arguments of every Call made plus bytes of every reply the net carried.  The reference counts gob bytes;
+ * here a message costs its fixed-width fields (RG_*_BYTES below) plus, per log entry, 4 bytes of term and
+ * `command_bytes` of payload (the size the caller's commands have; the engine carries 8-byte handles). */
+#define RG_VOTE_ARGS_BYTES 16
+#define RG_VOTE_REPLY_BYTES 8
+#define RG_APPEND_ARGS_BYTES 24
+#define RG_APPEND_REPLY_BYTES 16
+int rg_rpc_bytes(rg_engine *e, int64_t command_bytes, uint64_t *total);   /* RG_ERR_STATE unless rg_config.account_bytes */
 /* Full log-matching and leader-completeness scan; ORs into the group flags. */
 int rg_safety_check(rg_engine *e);
 /* out[0] = OR of all group flag words, out[1] = number of flagged groups. */

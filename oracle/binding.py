@@ -47,6 +47,7 @@ def load(path=None):
         "ro_read_state": ([vp, i32, vp, i64], C.c_int), "ro_write_state": ([vp, i32, vp, i64], C.c_int),
         "ro_state_hash": ([vp, P(C.c_uint64), i64], C.c_int),
         "ro_counters": ([vp, P(C.c_uint64)], C.c_int),
+        "ro_rpc_bytes": ([vp, C.c_int64, P(C.c_uint64)], C.c_int),
         "ro_safety_check": ([vp], C.c_int), "ro_safety_flags": ([vp, P(C.c_uint32)], C.c_int),
         "ro_snapshot_export": ([vp, i32, i32, vp, i64, P(i64)], C.c_int),
         "ro_snapshot_import": ([vp, i32, i32, vp, i64], C.c_int),

@@ -233,19 +233,21 @@ static void append_entries(ro_engine *e, ctr_t *c, group_t *g, peer_t *rf, int32
 /* ---------------- network (labrpc.go:216-307) --------------------------- */
 enum { NET_LOST = 0, NET_REPLY_LOST = 1, NET_OK = 2 };
 
-static int net_outcome(const ro_engine *e, const group_t *g, int s, int j, uint32_t seq, int32_t *cost) {
+static int net_outcome(const ro_engine *e, const group_t *g, int s, int j, uint32_t seq, int32_t *cost, int *wire) {
   const peer_t *a = &g->peer[s], *b = &g->peer[j];
   *cost = RG_RPC_WAIT_MS;
+  *wire = 0;                      /* does the reply travel (and count its bytes, labrpc.go:286-290), in time or not */
   if (!(a->connected && b->connected && a->side == b->side) || b->dead) return NET_LOST;
   const rg_config *cf = &e->cfg;
-  if (cf->req_drop_permille == 0 && cf->reply_drop_permille == 0 && cf->reply_delay_permille == 0) { *cost = 0; return NET_OK; }
+  if (cf->req_drop_permille == 0 && cf->reply_drop_permille == 0 && cf->reply_delay_permille == 0) { *cost = 0; *wire = 1; return NET_OK; }
   uint64_t h = stream_hash(g->key, STREAM_NET, ((uint32_t)s << 8) | (uint32_t)j, seq);
   /* the delays of one round come from one hash, 8 bits per target */
   uint64_t delays = stream_hash(g->key, STREAM_NET, 0xFFFF0000u | (uint32_t)s, seq);
   int32_t d = (int32_t)((((delays >> (8 * j)) & 0xFF) * RG_NET_DELAY_SPAN_MS) >> 8);         /* :222, 0..26 */
   if ((int32_t)((h & 0xFFFFF) % 1000) < cf->req_drop_permille) return NET_LOST;              /* :226 */
+  *wire = !((int32_t)(((h >> 20) & 0xFFFFF) % 1000) < cf->reply_drop_permille);              /* :273 */
   if (d >= RG_RPC_WAIT_MS) return NET_REPLY_LOST;                    /* handler runs, the sender has given up */
-  if ((int32_t)(((h >> 20) & 0xFFFFF) % 1000) < cf->reply_drop_permille) return NET_REPLY_LOST;   /* :273 */
+  if (!*wire) return NET_REPLY_LOST;
   if ((int32_t)(((h >> 40) & 0xFFFFF) % 1000) < cf->reply_delay_permille) return NET_REPLY_LOST;  /* :276 */
   *cost = d;
   return NET_OK;
@@ -299,9 +301,11 @@ static void election_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t no
     for (int i = 0; i < l && state == RG_CANDIDATE; i++) {
       state = rf->state;
       if (i != me) {
-        int out = net_outcome(e, g, me, i, seq, &cost);
+        int onWire;
+        int out = net_outcome(e, g, me, i, seq, &cost, &onWire);
         busy += cost;
         c->c[RG_C_RPC_SENT]++;
+        if (e->cfg.account_bytes) c->c[RG_C_RPC_FIXED_BYTES] += RG_VOTE_ARGS_BYTES + (onWire ? RG_VOTE_REPLY_BYTES : 0);
         int ok = 0;
         if (out != NET_LOST) {
           rg_vote_reply wire = { 0, 0 };
@@ -418,9 +422,14 @@ static void monitor_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t now
           break;                                                    /* :451-454 */
         }
         rg_append_reply reply = { 0, 0, 0, 0 };
-        int out = net_outcome(e, g, me, i, seq, &cost);
+        int onWire;
+        int out = net_outcome(e, g, me, i, seq, &cost, &onWire);
         busy += cost;
         c->c[RG_C_RPC_SENT]++;
+        if (e->cfg.account_bytes) {
+          c->c[RG_C_RPC_FIXED_BYTES] += RG_APPEND_ARGS_BYTES + (onWire ? RG_APPEND_REPLY_BYTES : 0);
+          c->c[RG_C_AE_ENTRIES_SENT] += (uint64_t)args.n_entries;
+        }
         int ok = 0;
         if (out != NET_LOST) {
           append_entries(e, c, g, &g->peer[i], now, &args, rf->logTerm + args.entry_off, rf->logCmd + args.entry_off, &reply);
@@ -881,6 +890,15 @@ int ro_state_hash(ro_engine *e, uint64_t *out, int64_t n) {
 int ro_counters(ro_engine *e, uint64_t *out) {
   if (!e || !out) return RG_ERR_ARG;
   memcpy(out, e->counters, sizeof e->counters);
+  return RG_OK;
+}
+
+/* cfg.bytesTotal() under the fixed-width size model of include/raftgpu.h (labrpc.go:153-154,286-290) */
+int ro_rpc_bytes(ro_engine *e, int64_t command_bytes, uint64_t *total) {
+  if (!e || !total || command_bytes < 0) return RG_ERR_ARG;
+  if (!e->cfg.account_bytes) return RG_ERR_STATE;
+  const uint64_t *c = e->counters;
+  *total = c[RG_C_RPC_FIXED_BYTES] + (4 + (uint64_t)command_bytes) * c[RG_C_AE_ENTRIES_SENT];
   return RG_OK;
 }
 

@@ -54,6 +54,7 @@ int ro_read_state(ro_engine *e, int32_t field, void *dst, int64_t dst_bytes);
 int ro_write_state(ro_engine *e, int32_t field, const void *src, int64_t src_bytes);
 int ro_state_hash(ro_engine *e, uint64_t *out, int64_t n_groups);
 int ro_counters(ro_engine *e, uint64_t *out);
+int ro_rpc_bytes(ro_engine *e, int64_t command_bytes, uint64_t *total);
 int ro_safety_check(ro_engine *e);
 int ro_safety_flags(ro_engine *e, uint32_t *out);
 

@@ -11,19 +11,19 @@ if mode == "bench":
     kw.update(req_drop_permille=100, reply_drop_permille=100, start_period=5, start_max=1000, part_period=100, part_jitter=20)
 e = Engine(_abi.make_config(**kw))
 e.step(T); e.sync()
-buf = (C.c_uint64 * 48)()
+buf = (C.c_uint64 * 56)()
 e._lib.rg_debug_section_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 assert e._lib.rg_debug_section_counts(e._h, buf) == 0
 wt = ((G + 11) // 12) * T   # 12 five-peer groups per wave
 names = ["control", "classify", "(rest of actors)", "apply", "leader check", "pend header+election", "RV section", "monitor eval", "AE section"]
 cnt = {"pend header+election": 0, "RV section": 1, "monitor eval": 2, "AE section": 3, "apply": 4}
-tot = sum(buf[32:41])
+tot = sum(buf[40:49])
 for i, n in enumerate(names):
     extra = ""
     if n in cnt and buf[_abi.N_COUNTERS + cnt[n]]:
         k = buf[_abi.N_COUNTERS + cnt[n]]
-        extra = "  %.3f runs per wave-tick, %7.0f cycles per run" % (k / wt, buf[32 + i] / k)
-    print("%-22s %8.1f cycles per wave-tick (%4.1f %%)%s" % (n, buf[32 + i] / wt, 100.0 * buf[32 + i] / tot, extra))
+        extra = "  %.3f runs per wave-tick, %7.0f cycles per run" % (k / wt, buf[40 + i] / k)
+    print("%-22s %8.1f cycles per wave-tick (%4.1f %%)%s" % (n, buf[40 + i] / wt, 100.0 * buf[40 + i] / tot, extra))
 print("total                  %8.1f cycles per wave-tick" % (tot / wt))
 extra = {7: "store fences", 8: "AE: matrix cache miss", 9: "AE: prevTerm from HBM", 10: "AE: entries from HBM", 11: "AE: backoff scan",
          12: "apply: check by the wave", 13: "apply: record by the wave", 5: "Start", 6: "two-leader check"}

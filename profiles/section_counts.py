@@ -8,7 +8,7 @@ G, T = 65536, 20000
 e = Engine(_abi.make_config(n_groups=G, n_peers=5, log_cap=1024, seed=2, req_drop_permille=100, reply_drop_permille=100,
                             start_period=5, start_max=1000, part_period=100, part_jitter=20))
 e.step(T); e.sync()
-buf = (C.c_uint64 * 32)()
+buf = (C.c_uint64 * 56)()
 e._lib.rg_debug_section_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 assert e._lib.rg_debug_section_counts(e._h, buf) == 0
 wt = G * 8 // 64 * T

@@ -29,6 +29,7 @@ COUNTERS = [
     "elections_won", "ae_rounds", "entries_started", "entries_replicated",
     "entries_committed", "entries_applied", "persists", "persist_entries",
     "timeouts", "ae_conflicts", "stepdowns", "ae_delivered",
+    "rpc_fixed_bytes", "ae_entries_sent",
 ]
 N_COUNTERS = len(COUNTERS)
 
@@ -60,7 +61,7 @@ class Config(C.Structure):
         ("part_period", C.c_int32), ("part_jitter", C.c_int32),
         ("churn_period", C.c_int32), ("churn_disconnect_permille", C.c_int32),
         ("churn_restart_permille", C.c_int32), ("churn_crash_permille", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("account_bytes", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
     def as_dict(self):
@@ -110,7 +111,7 @@ EXPORTS = [
     "rg_step", "rg_sync", "rg_now", "rg_step_time_ms", "rg_start", "rg_start_batch", "rg_get_state",
     "rg_set_connected", "rg_set_side", "rg_crash", "rg_restart", "rg_set_unreliable", "rg_drain_applied",
     "rg_snapshot_export", "rg_snapshot_import", "rg_rpc_request_vote", "rg_rpc_append_entries",
-    "rg_read_state", "rg_write_state", "rg_state_hash", "rg_counters", "rg_safety_check", "rg_safety_flags",
+    "rg_read_state", "rg_write_state", "rg_state_hash", "rg_counters", "rg_rpc_bytes", "rg_safety_check", "rg_safety_flags",
     "rg_device_buffers",
 ]
 
@@ -157,6 +158,7 @@ def load_library(path=None):
         "rg_write_state": ([vp, i32, vp, i64], C.c_int),
         "rg_state_hash": ([vp, P(C.c_uint64), i64], C.c_int),
         "rg_counters": ([vp, P(C.c_uint64)], C.c_int),
+        "rg_rpc_bytes": ([vp, i64, P(C.c_uint64)], C.c_int),
         "rg_safety_check": ([vp], C.c_int),
         "rg_safety_flags": ([vp, P(C.c_uint32)], C.c_int),
         "rg_device_buffers": ([vp, P(vp), P(vp)], C.c_int),

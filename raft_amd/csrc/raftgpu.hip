@@ -62,6 +62,7 @@ struct DevCfg {
   int startPeriod, startFirst, startMax, startMode;
   int partPeriod, partJitter;
   int churnPeriod, churnDisc, churnRestart, churnCrash;
+  int acctBytes;
 };
 
 // packed per-peer flag word
@@ -112,15 +113,15 @@ __host__ __device__ static inline u64 elem_hash(unsigned peer, unsigned field, u
 __device__ static inline void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
 // per-wave counter block in LDS
-#define RG_CTR_SLOTS 48   // RG_N_COUNTERS public counters, then profiling slots (builds with -DRG_SECTION_COUNTS)
+#define RG_CTR_SLOTS 56   // RG_N_COUNTERS public counters, then profiling slots (builds with -DRG_SECTION_COUNTS)
 struct WaveCtr { unsigned c[RG_CTR_SLOTS]; };
 #ifdef RG_SECTION_COUNTS
 #define SECTION_COUNT(w, i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&(w)->c[RG_N_COUNTERS + (i)], 1u); } while (0)
 #else
 #define SECTION_COUNT(w, i) do { } while (0)
 #endif
-#ifdef RG_STAMPS   // diagnostic builds only: shader cycles per phase of a tick, summed per wave into slots 32..
-#define STAMP(k) do { unsigned long long _n = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&w->c[32 + (k)], (unsigned)(_n - _stamp)); _stamp = _n; } while (0)
+#ifdef RG_STAMPS   // diagnostic builds only: shader cycles per phase of a tick, summed per wave into slots 40..
+#define STAMP(k) do { unsigned long long _n = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&w->c[40 + (k)], (unsigned)(_n - _stamp)); _stamp = _n; } while (0)
 #define STAMP_INIT unsigned long long _stamp = __builtin_readcyclecounter()
 #else
 #define STAMP(k) do { } while (0)
@@ -417,16 +418,18 @@ __device__ static inline u64 round_delays(const DevCfg &c, u64 key, int s, unsig
   return stream_hash(key, STREAM_NET, 0xFFFF0000u | (unsigned)s, seq);
 }
 __device__ static inline int delay_of(u64 delays, int j) { return (int)((((unsigned)(delays >> (8 * j)) & 0xFFu) * (unsigned)RG_NET_DELAY_SPAN_MS) >> 8); }
-// network outcome of one Call, labrpc.go:216-307: 0 lost, 1 handler ran / reply lost, 2 round trip
+// network outcome of one Call, labrpc.go:216-307: 0 lost, 1 handler ran / reply lost or late, 2 round trip;
+// bit 2 (NET_WIRE): the net carried the reply, in time or not, and counted its bytes (labrpc.go:286-290)
+#define NET_WIRE 4
 __device__ static inline int net_outcome(const DevCfg &c, u64 key, bool reachable, int s, int j, unsigned seq, u64 delays) {
   if (!reachable) return 0;
-  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) return 2;
+  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) return 2 | NET_WIRE;
   u64 h = stream_hash(key, STREAM_NET, ((unsigned)s << 8) | (unsigned)j, seq);
   if ((int)((unsigned)(h & 0xFFFFF) % 1000u) < c.reqDrop) return 0;
-  if (delay_of(delays, j) >= RG_RPC_WAIT_MS) return 1;          // the handler runs, the sender has given up
   if ((int)((unsigned)((h >> 20) & 0xFFFFF) % 1000u) < c.replyDrop) return 1;
-  if ((int)((unsigned)((h >> 40) & 0xFFFFF) % 1000u) < c.replyDelay) return 1;
-  return 2;
+  if (delay_of(delays, j) >= RG_RPC_WAIT_MS) return 1 | NET_WIRE;   // the handler runs, the sender has given up
+  if ((int)((unsigned)((h >> 40) & 0xFFFFF) % 1000u) < c.replyDelay) return 1 | NET_WIRE;
+  return 2 | NET_WIRE;
 }
 // How long a round holds its sender: 25 ms for every Call without a reply (raft.go:473,608), else the net's delay.
 template <int P>
@@ -454,7 +457,8 @@ __device__ static inline int turn_start(u64 key, int tick, int P) {
 #ifndef RG_TICK_WAVES
 #define RG_TICK_WAVES 4   // waves per SIMD the register allocation must allow
 #endif
-template <int P>
+// BYTES: wire-byte accounting compiled in (rg_config.account_bytes); the plain instantiation carries none of it
+template <int P, bool BYTES>
 __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
   constexpr int PP = P <= 4 ? 4 : 8;        // stride of a group in the per-peer arrays and matrices in memory
   constexpr int NONE = 8;                   // "no such peer" for first-set-bit results
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #define rec(i) recBlk[rOff + (unsigned)(i)]
   const u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
-  __shared__ int coldLds[CD_N + 2][256];
+  __shared__ int coldLds[CD_N + (BYTES ? 4 : 2)][256];    // + two group words, + two per-lane byte-accounting sums
   // The last RING entries each peer wrote to its log, and the last RING records of each group, staged in LDS:
   // a follower copies a leader's fresh entries, and every peer applies its fresh entries, without a trip to
   // HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
@@ -509,6 +513,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #define gStartSeq coldLds[CD_N][threadIdx.x]
 #define gPartEpoch coldLds[CD_N + 1][threadIdx.x]
   gStartSeq = Sp->startSeq[gq]; gPartEpoch = Sp->partEpoch[gq];
+  if constexpr (BYTES) { coldLds[CD_N + 2][threadIdx.x] = 0; coldLds[CD_N + 3][threadIdx.x] = 0; }
   int partNext = Sp->partNext[gq], recMax = Sp->recMax[gq];
   unsigned gfl = 0;
   // next ticks of the periodic control events (kept as counters: no division in the loop)
@@ -689,7 +694,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           const bool tgt = inR && valid && peer != s;
           const bool reach = tgt && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
           const u64 delays = round_delays(c, key, sIdx, seq);
-          const int out = tgt ? net_outcome(c, key, reach, s, peer, seq, delays) : 0;
+          const int outW = tgt ? net_outcome(c, key, reach, s, peer, seq, delays) : 0;
+          const int out = outW & 3;
           VoteDecision d; d.rTerm = 0; d.touch = d.raise = d.grant = false;
           if (out != 0) d = decide_vote(r, r.cTerm, T, s, lli, llt);
           const unsigned sdm = G.ballot(out == 2 && d.rTerm > T);      // raft.go:622
@@ -701,6 +707,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             if (wasLead && d.touch && myPos > sPos && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok), grantM = G.ballot(ok && d.grant);
+          if constexpr (BYTES) atomicAdd((unsigned *)&coldLds[CD_N + 2][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
           const int busy = round_busy<P>(calledM, okM, delays);
           bool won = false;
           if (wantRV) {
@@ -809,7 +816,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           const bool tgt2 = tgt && peer < firstOv;
           const bool reach = tgt2 && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
           const u64 delays = round_delays(c, key, sIdx, seq);
-          const int out = tgt2 ? net_outcome(c, key, reach, s, peer, seq, delays) : 0;
+          const int outW = tgt2 ? net_outcome(c, key, reach, s, peer, seq, delays) : 0;
+          const int out = outW & 3;
           const int prev = nx - 1, k = lenS - nx;
           AppendDecision d; d.rTerm = 0; d.ct = 0; d.ci = 0; d.touch = d.match = false;
           int prevTerm = 0;
@@ -909,6 +917,10 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             nextRow(sIdx * PP + peer) = cNext;
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
+          if constexpr (BYTES) {   // wire bytes: summed per target lane in LDS words of its own, added to the counters when the launch ends
+            atomicAdd((unsigned *)&coldLds[CD_N + 2][tid], called ? (unsigned)RG_APPEND_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_APPEND_REPLY_BYTES : 0u) : 0u);
+            atomicAdd((unsigned *)&coldLds[CD_N + 3][tid], (called && k > 0) ? (unsigned)k : 0u);
+          }
           const int busy = round_busy<P>(calledM, okM, delays);
           int rTermB = 0;
           if (wave_any(b < NONE)) rTermB = G.shfl(d.rTerm, b < NONE ? b : 0);
@@ -1084,6 +1096,10 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #undef SYNC_STORES
 #undef RING_PUSH
   const int startSeqOut = gStartSeq, partEpochOut = gPartEpoch;
+  if constexpr (BYTES) {
+    if (coldLds[CD_N + 2][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 2][threadIdx.x]);
+    if (coldLds[CD_N + 3][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 3][threadIdx.x]);
+  }
 #undef gStartSeq
 #undef gPartEpoch
 #undef nextRow
@@ -1418,6 +1434,7 @@ static void fill_devcfg(rg_engine *e) {
   d.startPeriod = c.start_period; d.startFirst = c.start_first_tick; d.startMax = c.start_max; d.startMode = c.start_mode;
   d.partPeriod = c.part_period; d.partJitter = c.part_jitter;
   d.churnPeriod = c.churn_period; d.churnDisc = c.churn_disconnect_permille; d.churnRestart = c.churn_restart_permille; d.churnCrash = c.churn_crash_permille;
+  d.acctBytes = c.account_bytes != 0;
 }
 
 // Make for every peer: device memsets plus a host-built image of the few non-zero words.
@@ -1589,6 +1606,38 @@ static int run_derive(rg_engine *e) {
   return RG_OK;
 }
 
+// The per-wave counters of a launch are 32-bit words in LDS; the fastest of them (wire bytes) can grow by a few
+// thousand per tick, so one launch covers at most this many ticks.
+#define RG_MAX_LAUNCH_TICKS 500000
+
+static int launch_ticks(rg_engine *e, int n_ticks) {
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+  const int blocks = e->Gpad / e->gpb;
+  HIPCHK(hipEventRecord(a, e->stream));
+  const DevPtrs *dS = e->dS;
+#define TICK_LAUNCH(PEERS) do { \
+    if (e->dc.acctBytes) hipLaunchKernelGGL((k_tick<PEERS, true>), dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, n_ticks); \
+    else hipLaunchKernelGGL((k_tick<PEERS, false>), dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, n_ticks); } while (0)
+  switch (e->P) {
+  case 2: TICK_LAUNCH(2); break;
+  case 3: TICK_LAUNCH(3); break;
+  case 4: TICK_LAUNCH(4); break;
+  case 5: TICK_LAUNCH(5); break;
+  case 6: TICK_LAUNCH(6); break;
+  case 7: TICK_LAUNCH(7); break;
+  default: TICK_LAUNCH(8); break;
+  }
+#undef TICK_LAUNCH
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(b, e->stream));
+  e->pendingEv.push_back(std::make_pair(a, b));
+  e->launches++;
+  e->now += n_ticks;
+  // group-ticks are counted on the host side of the counter block
+  return RG_OK;
+}
+
 extern "C" int rg_step(rg_engine *e, int32_t n_ticks) {
   LOCK(e);
   if (n_ticks < 0) return RG_ERR_ARG;
@@ -1596,27 +1645,13 @@ extern "C" int rg_step(rg_engine *e, int32_t n_ticks) {
   if (e->now + n_ticks > 0x7ffffff0ll) return RG_ERR_RANGE;
   int rc = run_derive(e);
   if (rc != RG_OK) return rc;
-  if (e->pendingEv.size() >= 512) { rc = collect_events(e); if (rc != RG_OK) return rc; }
-  hipEvent_t a, b;
-  HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-  const int blocks = e->Gpad / e->gpb;
-  HIPCHK(hipEventRecord(a, e->stream));
-  const DevPtrs *dS = e->dS;
-  switch (e->P) {
-  case 2: hipLaunchKernelGGL(k_tick<2>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
-  case 3: hipLaunchKernelGGL(k_tick<3>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
-  case 4: hipLaunchKernelGGL(k_tick<4>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
-  case 5: hipLaunchKernelGGL(k_tick<5>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
-  case 6: hipLaunchKernelGGL(k_tick<6>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
-  case 7: hipLaunchKernelGGL(k_tick<7>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
-  default: hipLaunchKernelGGL(k_tick<8>, dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, (int)n_ticks); break;
+  while (n_ticks > 0) {
+    if (e->pendingEv.size() >= 512) { rc = collect_events(e); if (rc != RG_OK) return rc; }
+    const int n = n_ticks < RG_MAX_LAUNCH_TICKS ? n_ticks : RG_MAX_LAUNCH_TICKS;
+    rc = launch_ticks(e, n);
+    if (rc != RG_OK) return rc;
+    n_ticks -= n;
   }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(b, e->stream));
-  e->pendingEv.push_back(std::make_pair(a, b));
-  e->launches++;
-  e->now += n_ticks;
-  // group-ticks are counted on the host side of the counter block
   return RG_OK;
 }
 
@@ -2143,6 +2178,16 @@ extern "C" int rg_counters(rg_engine *e, uint64_t *out) {
   int rc = d2h(e, out, e->S.counters, RG_N_COUNTERS * 8);
   if (rc != RG_OK) return rc;
   out[RG_C_GROUP_TICKS] = (uint64_t)e->G * (uint64_t)e->now;
+  return RG_OK;
+}
+
+extern "C" int rg_rpc_bytes(rg_engine *e, int64_t command_bytes, uint64_t *total) {
+  if (!e || !total || command_bytes < 0) return RG_ERR_ARG;
+  if (!e->dc.acctBytes) return RG_ERR_STATE;
+  uint64_t c[RG_N_COUNTERS];
+  int rc = rg_counters(e, c);
+  if (rc != RG_OK) return rc;
+  *total = c[RG_C_RPC_FIXED_BYTES] + (4 + (uint64_t)command_bytes) * c[RG_C_AE_ENTRIES_SENT];
   return RG_OK;
 }
 

@@ -56,6 +56,12 @@ class EngineBase(object):
         self._check(self._fn("counters")(self._h, buf), "counters")
         return {n: int(buf[i]) for i, n in enumerate(COUNTERS)}
 
+    def rpc_bytes(self, command_bytes=8):
+        """cfg.bytesTotal(), src/raft/config.go:292-294, under the fixed-width size model of include/raftgpu.h."""
+        out = C.c_uint64()
+        self._check(self._fn("rpc_bytes")(self._h, int(command_bytes), C.byref(out)), "rpc_bytes")
+        return int(out.value)
+
     def safety_flags(self):
         buf = (C.c_uint32 * 2)()
         self._check(self._fn("safety_flags")(self._h, buf), "safety_flags")

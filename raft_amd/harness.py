@@ -107,6 +107,10 @@ class Config(object):
     def rpcTotal(self):
         return self.engine.counters()["rpc_sent"]
 
+    def bytesTotal(self, command_bytes=8):
+        """config.go:292-294; command_bytes = size of the commands the caller's handles stand for."""
+        return self.engine.rpc_bytes(command_bytes)
+
     def rpcCount(self):
         """Sum over servers of delivered requests (labrpc.go:406)."""
         return self.engine.counters()["rpc_delivered"]

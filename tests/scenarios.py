@@ -9,7 +9,7 @@ from raft_amd.harness import Config, TestFailure, ELECTION_TIMEOUT_TICKS as ET
 
 
 def _cfg(make_engine, servers, unreliable=False, log_cap=512, seed=1):
-    eng = make_engine(n_groups=1, n_peers=servers, log_cap=log_cap, seed=seed)
+    eng = make_engine(n_groups=1, n_peers=servers, log_cap=log_cap, seed=seed, account_bytes=1)
     return Config(eng, 0, unreliable)
 
 
@@ -51,6 +51,25 @@ def basic_agree_2b(make_engine):               # test_test.go:89-110
         assert nd == 0, "some have committed before Start()"
         xindex = cfg.one(index * 100, servers, False)
         assert xindex == index, "got index %d but expected %d" % (xindex, index)
+    return cfg
+
+
+def rpc_bytes_2b(make_engine):                 # test_test.go:112-145
+    """Each command travels to each peer just once: ten 5000-byte commands (the engine carries handles, the byte
+    count prices each entry at the size the caller states) cost at most servers x 50,000 bytes + 50,000."""
+    servers, size = 3, 5000
+    cfg = _cfg(make_engine, servers)
+    cfg.one(99, servers, False)
+    bytes0 = cfg.bytesTotal(size)
+    sent = 0
+    for index in range(2, 12):
+        xindex = cfg.one(1000 + index, servers, False)
+        assert xindex == index, "got index %d but expected %d" % (xindex, index)
+        sent += size
+    got = cfg.bytesTotal(size) - bytes0
+    expected = servers * sent
+    assert got <= expected + 50000, "too many RPC bytes; got %d, expected %d" % (got, expected)
+    assert got >= (servers - 1) * sent, "fewer bytes than one copy per follower (%d)" % got
     return cfg
 
 
@@ -438,7 +457,7 @@ def churn_2c(make_engine, unreliable, seed=6, iters=20):   # test_test.go:825-96
 
 ALL = {
     "InitialElection2A": initial_election_2a, "ReElection2A": reelection_2a, "BasicAgree2B": basic_agree_2b,
-    "FailAgree2B": fail_agree_2b, "FailNoAgree2B": fail_no_agree_2b, "ConcurrentStarts2B": concurrent_starts_2b,
+    "RPCBytes2B": rpc_bytes_2b, "FailAgree2B": fail_agree_2b, "FailNoAgree2B": fail_no_agree_2b, "ConcurrentStarts2B": concurrent_starts_2b,
     "Rejoin2B": rejoin_2b, "Backup2B": backup_2b, "Count2B": count_2b, "Persist12C": persist1_2c,
     "Persist22C": persist2_2c, "Persist32C": persist3_2c, "Figure82C": figure8_2c,
     "UnreliableAgree2C": unreliable_agree_2c, "Figure8Unreliable2C": figure8_unreliable_2c,

@@ -30,7 +30,7 @@ def test_lossless_workload(peers):
 @pytest.mark.parametrize("peers,seed", [(5, 2), (3, 9), (7, 4)])
 def test_unreliable_rolling_partitions(peers, seed):
     o, e = _pair(n_groups=64, n_peers=peers, log_cap=256, seed=seed, req_drop_permille=100, reply_drop_permille=100,
-                 start_period=5, start_max=200, part_period=100, part_jitter=20)
+                 start_period=5, start_max=200, part_period=100, part_jitter=20, account_bytes=1)
     run_lockstep(o, e, [1] * 300 + [13] * 100 + [500] * 4)
     assert o.safety_check() == e.safety_check()
 
@@ -47,5 +47,6 @@ def test_churn_crash_restart(peers, seed, mode):
 def test_long_reordering_and_heavy_loss():
     o, e = _pair(n_groups=32, n_peers=5, log_cap=256, seed=11, req_drop_permille=300, reply_drop_permille=300,
                  reply_delay_permille=667, start_period=2, start_max=250, start_mode=_abi.START_ALL,
-                 part_period=37, part_jitter=11)
+                 part_period=37, part_jitter=11, account_bytes=1)
     run_lockstep(o, e, [1] * 500 + [250] * 6)
+    assert o.rpc_bytes(100) == e.rpc_bytes(100) > 0
