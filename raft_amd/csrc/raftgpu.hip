@@ -335,7 +335,7 @@ struct Grp {
     unsigned lo = shflu((unsigned)v, j), hi = shflu((unsigned)(v >> 32), j);
     return ((u64)hi << 32) | lo;
   }
-  __device__ unsigned ballot(bool p) const { return (unsigned)(__ballot(p) >> base) & ((1u << PP) - 1u); }
+  __device__ unsigned ballot(bool p) const { return (unsigned)(__builtin_amdgcn_ballot_w64(p) >> base) & ((1u << PP) - 1u); }
   __device__ int gmin(int v) const {
 #pragma unroll
     for (int m = 1; m < PP; m <<= 1) { int o = __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, v); v = o < v ? o : v; }
@@ -379,7 +379,7 @@ struct GrpN {
     unsigned lo = shflu((unsigned)v, j), hi = shflu((unsigned)(v >> 32), j);
     return ((u64)hi << 32) | lo;
   }
-  __device__ unsigned ballot(bool p) const { return (unsigned)(__ballot(p) >> base) & ((1u << P) - 1u); }
+  __device__ unsigned ballot(bool p) const { return (unsigned)(__builtin_amdgcn_ballot_w64(p) >> base) & ((1u << P) - 1u); }
   // idempotent reductions: doubling rotations cover the group in ceil(log2 P) steps
   __device__ int gmin(int v) const {
 #pragma unroll
@@ -410,7 +410,7 @@ struct GrpN {
   }
 };
 
-__device__ static inline bool wave_any(bool p) { return __ballot(p) != 0ull; }
+__device__ static inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // The unreliable net's delays of one round, 8 bits per target (labrpc.go:222): one hash per round, so the
 // sender can add up its waits without asking the targets.
 __device__ static inline u64 round_delays(const DevCfg &c, u64 key, int s, unsigned seq) {
@@ -852,10 +852,13 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           if (ran && d.touch && d.match && k > 0) {
             viaHbm = k > RING;
 #pragma unroll
-            for (int j = 0; j < RING; j++) if (j < k && ringIdx[(nx + j) & (RING - 1)][sTid] != nx + j) viaHbm = true;
+            for (int q = 0; q < RING; q++) {               // slot q would hold the one index of nx..nx+3 that is q mod RING
+              const int want = nx + ((q - nx) & (RING - 1));
+              if (want < lenS && ringIdx[q][sTid] != want) viaHbm = true;
+            }
           }
           {
-            u64 hm = __ballot(viaHbm);
+            u64 hm = __builtin_amdgcn_ballot_w64(viaHbm);
             const bool scan = ok && b != peer && d.touch && !d.match;
             if (hm) SECTION_COUNT(w, 10);
             if (wave_any(scan)) SECTION_COUNT(w, 11);
@@ -986,8 +989,11 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         if (wave_any(nRec > 0)) {
           bool slow = nRec > RING;
 #pragma unroll
-          for (int j = 0; j < RING; j++) if (j < nRec && ringIdx[(recLo + 1 + j) & (RING - 1)][tid] != recLo + 1 + j) slow = true;
-          u64 sm = __ballot(slow);
+          for (int q = 0; q < RING; q++) {
+            const int want = recLo + 1 + ((q - recLo - 1) & (RING - 1));
+            if (want <= r.commit && nRec > 0 && ringIdx[q][tid] != want) slow = true;
+          }
+          u64 sm = __builtin_amdgcn_ballot_w64(slow);
           if (nRec > 0 && !slow) {
             for (int j = 0; j < nRec; j++) {
               const int i = recLo + 1 + j, q = i & (RING - 1);
@@ -1027,11 +1033,11 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         if (wave_any(nCmp > 0)) {
           bool slow = nCmp > RING;
 #pragma unroll
-          for (int j = 0; j < RING; j++) {
-            const int i = r.applied + 1 + j, q = i & (RING - 1);
-            if (j < nCmp && !(ringIdx[q][tid] == i && recIdx[q][gLoc] == i)) slow = true;
+          for (int q = 0; q < RING; q++) {
+            const int want = r.applied + 1 + ((q - r.applied - 1) & (RING - 1));
+            if (want <= cmpHi && nCmp > 0 && !(ringIdx[q][tid] == want && recIdx[q][gLoc] == want)) slow = true;
           }
-          u64 sm = __ballot(slow);
+          u64 sm = __builtin_amdgcn_ballot_w64(slow);
           if (nCmp > 0 && !slow) {
             for (int j = 0; j < nCmp; j++) {
               const int i = r.applied + 1 + j, q = i & (RING - 1);
