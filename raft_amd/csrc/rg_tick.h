@@ -1,0 +1,806 @@
+// rg_tick.h -- the tick kernel: n lockstep ticks of every group in one launch (needs rg_state.h)
+#ifndef RG_TICK_H
+#define RG_TICK_H
+
+// ---------------------------------------------------------------- tick kernel
+template <int PP>
+struct Grp {
+  int lane, base, peer;
+  __device__ Grp() {
+    lane = (int)(threadIdx.x & 63);
+    base = lane & ~(PP - 1);
+    peer = lane & (PP - 1);
+  }
+  __device__ int shfl(int v, int j) const { return __builtin_amdgcn_ds_bpermute((base | j) << 2, v); }
+  __device__ unsigned shflu(unsigned v, int j) const { return (unsigned)__builtin_amdgcn_ds_bpermute((base | j) << 2, (int)v); }
+  __device__ u64 shfl64(u64 v, int j) const {
+    unsigned lo = shflu((unsigned)v, j), hi = shflu((unsigned)(v >> 32), j);
+    return ((u64)hi << 32) | lo;
+  }
+  __device__ unsigned ballot(bool p) const { return (unsigned)(__builtin_amdgcn_ballot_w64(p) >> base) & ((1u << PP) - 1u); }
+  __device__ int gmin(int v) const {
+#pragma unroll
+    for (int m = 1; m < PP; m <<= 1) { int o = __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, v); v = o < v ? o : v; }
+    return v;
+  }
+  __device__ int gmax(int v) const {
+#pragma unroll
+    for (int m = 1; m < PP; m <<= 1) { int o = __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, v); v = o > v ? o : v; }
+    return v;
+  }
+  __device__ int gsum(int v) const {
+#pragma unroll
+    for (int m = 1; m < PP; m <<= 1) v += __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, v);
+    return v;
+  }
+  __device__ unsigned gor(unsigned v) const {
+#pragma unroll
+    for (int m = 1; m < PP; m <<= 1) v |= (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ m) << 2, (int)v);
+    return v;
+  }
+};
+
+// Dense variant for the tick kernel: a group's P peers sit in P adjacent lanes, 64/P whole groups per
+// wave (12 for P = 5) and the 64 % P tail lanes idle, instead of padding every group to a power of two.
+template <int P>
+struct GrpN {
+  static constexpr int GW = 64 / P;          // groups per wave
+  int lane, base, peer;
+  bool inWave;
+  __device__ GrpN() {
+    lane = (int)(threadIdx.x & 63);
+    const int q = lane / P;
+    base = q * P;
+    peer = lane - base;
+    inWave = q < GW;
+  }
+  __device__ int rot(int d) const { int x = peer + d; return base + (x >= P ? x - P : x); }
+  __device__ int shfl(int v, int j) const { return __builtin_amdgcn_ds_bpermute((base + j) << 2, v); }
+  __device__ unsigned shflu(unsigned v, int j) const { return (unsigned)__builtin_amdgcn_ds_bpermute((base + j) << 2, (int)v); }
+  __device__ u64 shfl64(u64 v, int j) const {
+    unsigned lo = shflu((unsigned)v, j), hi = shflu((unsigned)(v >> 32), j);
+    return ((u64)hi << 32) | lo;
+  }
+  __device__ unsigned ballot(bool p) const { return (unsigned)(__builtin_amdgcn_ballot_w64(p) >> base) & ((1u << P) - 1u); }
+  // idempotent reductions: doubling rotations cover the group in ceil(log2 P) steps
+  __device__ int gmin(int v) const {
+#pragma unroll
+    for (int d = 1; d < P; d <<= 1) { int o = __builtin_amdgcn_ds_bpermute(rot(d) << 2, v); v = o < v ? o : v; }
+    return v;
+  }
+  __device__ int gmax(int v) const {
+#pragma unroll
+    for (int d = 1; d < P; d <<= 1) { int o = __builtin_amdgcn_ds_bpermute(rot(d) << 2, v); v = o > v ? o : v; }
+    return v;
+  }
+  __device__ unsigned gor(unsigned v) const {
+#pragma unroll
+    for (int d = 1; d < P; d <<= 1) v |= (unsigned)__builtin_amdgcn_ds_bpermute(rot(d) << 2, (int)v);
+    return v;
+  }
+  __device__ int gsum(int v) const {
+    if constexpr ((P & (P - 1)) == 0) {
+#pragma unroll
+      for (int d = 1; d < P; d <<= 1) v += __builtin_amdgcn_ds_bpermute(rot(d) << 2, v);
+      return v;
+    } else {
+      int t = v;
+#pragma unroll
+      for (int d = 1; d < P; d++) t += __builtin_amdgcn_ds_bpermute(rot(d) << 2, v);
+      return t;
+    }
+  }
+};
+
+__device__ static inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// The unreliable net's delays of one round, 8 bits per target (labrpc.go:222): one hash per round, so the
+// sender can add up its waits without asking the targets.
+__device__ static inline u64 round_delays(const DevCfg &c, u64 key, int s, unsigned seq) {
+  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) return 0;
+  return stream_hash(key, STREAM_NET, 0xFFFF0000u | (unsigned)s, seq);
+}
+__device__ static inline int delay_of(u64 delays, int j) { return (int)((((unsigned)(delays >> (8 * j)) & 0xFFu) * (unsigned)RG_NET_DELAY_SPAN_MS) >> 8); }
+// network outcome of one Call, labrpc.go:216-307: 0 lost, 1 handler ran / reply lost or late, 2 round trip;
+// bit 2 (NET_WIRE): the net carried the reply, in time or not, and counted its bytes (labrpc.go:286-290)
+#define NET_WIRE 4
+__device__ static inline int net_outcome(const DevCfg &c, u64 key, bool reachable, int s, int j, unsigned seq, u64 delays) {
+  if (!reachable) return 0;
+  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) return 2 | NET_WIRE;
+  u64 h = stream_hash(key, STREAM_NET, ((unsigned)s << 8) | (unsigned)j, seq);
+  if ((int)((unsigned)(h & 0xFFFFF) % 1000u) < c.reqDrop) return 0;
+  if ((int)((unsigned)((h >> 20) & 0xFFFFF) % 1000u) < c.replyDrop) return 1;
+  if (delay_of(delays, j) >= RG_RPC_WAIT_MS) return 1 | NET_WIRE;   // the handler runs, the sender has given up
+  if ((int)((unsigned)((h >> 40) & 0xFFFFF) % 1000u) < c.replyDelay) return 1 | NET_WIRE;
+  return 2 | NET_WIRE;
+}
+// How long a round holds its sender: 25 ms for every Call without a reply (raft.go:473,608), else the net's delay.
+template <int P>
+__device__ static inline int round_busy(unsigned calledM, unsigned okM, u64 delays) {
+  int busy = 0;
+#pragma unroll
+  for (int j = 0; j < P; j++)
+    if ((calledM >> j) & 1u) busy += ((okM >> j) & 1u) ? delay_of(delays, j) : RG_RPC_WAIT_MS;
+  return busy;
+}
+
+// scheduler slack of the election loop's 50 ms sleep: 0..3 ms, seeded
+__device__ static inline int sleep_slack(u64 key, int p, int now) {
+  unsigned h = (unsigned)key ^ ((unsigned)p * 0x9E3779B1u) ^ ((unsigned)now * 0x85EBCA6Bu);
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return (int)(h >> 30);
+}
+// first peer of a tick's actor order
+__device__ static inline int turn_start(u64 key, int tick, int P) {
+  unsigned h = (unsigned)tick * 0x9E3779B1u + (unsigned)key;
+  h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+  return (int)(((h >> 16) * (unsigned)P) >> 16);
+}
+
+#ifndef RG_TICK_WAVES
+#define RG_TICK_WAVES 4   // waves per SIMD the register allocation must allow
+#endif
+// BYTES: wire-byte accounting compiled in (rg_config.account_bytes); the plain instantiation carries none of it
+template <int P, bool BYTES>
+__global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
+  constexpr int PP = P <= 4 ? 4 : 8;        // stride of a group in the per-peer arrays and matrices in memory
+  constexpr int NONE = 8;                   // "no such peer" for first-set-bit results
+  constexpr int GW = GrpN<P>::GW;
+  constexpr int GPB = 4 * GW;               // groups per 256-thread block
+  __shared__ WaveCtr sctr[4];
+  const GrpN<P> G;
+  const int wave = (int)(threadIdx.x >> 6);
+  WaveCtr *w = &sctr[wave];
+  if (G.lane < RG_CTR_SLOTS) w->c[G.lane] = 0;
+  __syncthreads();
+
+  const int g0 = (int)blockIdx.x * GPB;                        // the block's first group: always < G
+  const int g = g0 + wave * GW + (G.lane / P);
+  const int peer = G.peer;
+  const bool valid = G.inWave && g < c.G;
+  const int L = c.L;
+  const unsigned gLoc = valid ? (unsigned)(g - g0) : 0u;       // in-range group for address arithmetic of idle lanes
+  const int gq = g0 + (int)gLoc;
+  const long long gl = (long long)(G.inWave ? g : g0) * PP + (G.inWave ? peer : 0);   // slot in the per-peer arrays
+  Rows lg, sn;
+  lg.base = H.logRows + (size_t)g0 * L * c.rowBytes; lg.off = gLoc * (unsigned)L * (unsigned)c.rowBytes; lg.rowBytes = c.rowBytes; lg.cmdOff = c.cmdOff;
+  sn = lg; sn.base = H.snapRows + (size_t)g0 * L * c.rowBytes;
+  int *const nextBlk = H.nextIdx + (size_t)g0 * PP * PP;       // uniform; rows [group][owner][j]
+  int *const matchBlk = H.matchIdx + (size_t)g0 * PP * PP;
+  const unsigned mOff = gLoc * (unsigned)(PP * PP);
+#define nextRow(i) nextBlk[mOff + (unsigned)(i)]
+#define matchRow(i) matchBlk[mOff + (unsigned)(i)]
+  u64 *const recBlk = H.applyRec + (size_t)g0 * L;
+  const unsigned rOff = gLoc * (unsigned)L;
+#define rec(i) recBlk[rOff + (unsigned)(i)]
+  const u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
+
+  __shared__ int coldLds[CD_N + (BYTES ? 4 : 2)][256];    // + two group words, + two per-lane byte-accounting sums
+  // The last RING entries each peer wrote to its log, and the last RING records of each group, staged in LDS:
+  // a follower copies a leader's fresh entries, and every peer applies its fresh entries, without a trip to
+  // HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
+  constexpr int RING = 4;
+  __shared__ int ringIdx[RING][256];
+  __shared__ int ringTerm[RING][256];
+  __shared__ u64 ringCmd[RING][256];
+  __shared__ int recIdx[RING][GPB];
+  __shared__ u64 recVal[RING][GPB];
+  const int tid = (int)threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < RING; q++) { ringIdx[q][tid] = -1; if (tid < GPB) recIdx[q][tid] = -1; }
+  __syncthreads();
+#define RING_PUSH(i_, tm_, cm_) do { const int _q = (i_) & (RING - 1); ringIdx[_q][tid] = (i_); ringTerm[_q][tid] = (tm_); ringCmd[_q][tid] = (cm_); } while (0)
+  LaneT<lds_int *> r;
+  r.cold = (lds_int *)&coldLds[0][threadIdx.x]; r.cs = 256;
+  r.load(*Sp, gl);                       // tail lanes read a valid slot and never write it back
+#define gStartSeq coldLds[CD_N][threadIdx.x]
+#define gPartEpoch coldLds[CD_N + 1][threadIdx.x]
+  gStartSeq = Sp->startSeq[gq]; gPartEpoch = Sp->partEpoch[gq];
+  if constexpr (BYTES) { coldLds[CD_N + 2][threadIdx.x] = 0; coldLds[CD_N + 3][threadIdx.x] = 0; }
+  int partNext = Sp->partNext[gq], recMax = Sp->recMax[gq];
+  unsigned gfl = 0;
+  // next ticks of the periodic control events (kept as counters: no division in the loop)
+  // Within a launch each lane caches the nextIndex / matchIndex words ONE leader (cOwner) keeps for it; memory is
+  // written through, so the matrices in HBM stay complete for other owners, dumps and digests.
+  int cOwner = -1, cNext = 0, cMatch = 0;
+  // stores to words another lane may read later are drained (vmcnt) only right before such a read
+  bool storesPending = false;
+#define SYNC_STORES() do { if (storesPending) { SECTION_COUNT(w, 7); wave_fence(); storesPending = false; } } while (0)
+  bool chkLeaders = true;      // the one-leader check is re-evaluated only after something changed
+  int nextStartTick = 0x7fffffff, nextChurnTick = 0x7fffffff, churnIt = 0;
+  if (c.startPeriod > 0) {
+    nextStartTick = c.startFirst;
+    if (t0 > c.startFirst) nextStartTick += (t0 - c.startFirst + c.startPeriod - 1) / c.startPeriod * c.startPeriod;
+  }
+  if (c.churnPeriod > 0) {
+    int from = t0 > 1 ? t0 : 1;
+    churnIt = (from + c.churnPeriod - 1) / c.churnPeriod;
+    nextChurnTick = churnIt * c.churnPeriod;
+  }
+
+  __builtin_amdgcn_s_waitcnt(0);         // nothing of the prologue is in flight when the loop starts
+  for (int t = t0; t < t0 + nticks; t++) {
+    const int now = t * RG_TICK_MS;
+    STAMP_INIT;
+    // ------------------------------------------------------------ 1. control
+    if (c.partPeriod > 0 && wave_any(t == partNext)) chkLeaders = true;
+    if (c.partPeriod > 0 && t == partNext) {
+      unsigned ep = (unsigned)gPartEpoch;
+      r.set(F_SIDE, (stream_hash(key, STREAM_PART, ep, (unsigned)peer + 1) & 1) != 0);
+      u64 h = stream_hash(key, STREAM_PART, ep, 0);
+      partNext = t + c.partPeriod + (c.partJitter > 0 ? (int)(h % (u64)c.partJitter) : 0);
+      gPartEpoch++;
+    }
+    if (t == nextChurnTick) {                                        // test_test.go:893-919
+      unsigned it = (unsigned)churnIt;
+      churnIt++; nextChurnTick += c.churnPeriod;
+      chkLeaders = true; storesPending = true;
+      u64 h1 = stream_hash(key, STREAM_CHURN, it, 0), h2 = stream_hash(key, STREAM_CHURN, it, 1), h3 = stream_hash(key, STREAM_CHURN, it, 2);
+      if ((int)((unsigned)(h1 & 0xFFFFF) % 1000u) < c.churnDisc && peer == (int)((h1 >> 32) % (u64)P)) r.flags &= ~F_CONNECTED;
+      if ((int)((unsigned)(h2 & 0xFFFFF) % 1000u) < c.churnRestart && valid && peer == (int)((h2 >> 32) % (u64)P)) {
+        if (r.has(F_DEAD)) {
+          make_peer(r, lg, sn, peer, L, key, now, w);
+#pragma unroll
+          for (int q = 0; q < RING; q++) ringIdx[q][tid] = -1;     // the log may have been rebuilt from an imported blob
+        }
+        r.flags |= F_CONNECTED;
+      }
+      if ((int)((unsigned)(h3 & 0xFFFFF) % 1000u) < c.churnCrash && peer == (int)((h3 >> 32) % (u64)P) && !r.has(F_DEAD)) {
+        r.flags &= ~F_CONNECTED;
+        r.flags |= F_DEAD;
+      }
+    }
+    if (t == nextStartTick) {
+      nextStartTick += c.startPeriod;
+      // client Starts: config.go:436-451 (first connected leader) / test_test.go:697-703 (every leader)
+      bool cand = valid && r.isLeader() && (c.startMode == RG_START_ALL || r.has(F_CONNECTED));
+      if (wave_any(cand)) {
+        SECTION_COUNT(w, 5);
+        bool room = cand && r.logLen < L;
+        unsigned mAll = G.ballot(cand), mRoom = G.ballot(room);
+        unsigned below = (1u << peer) - 1u;
+        if (c.startMode == RG_START_ALL) {
+          int seq = gStartSeq + __popc(mRoom & below);
+          bool tried = cand && seq < c.startMax;
+          if (tried) {
+            u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)seq);
+            const int at = start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
+            if (at >= 0) RING_PUSH(at, r.term, cmd);
+          }
+          int acc = __popc(mRoom);
+          int left = c.startMax - gStartSeq;
+          gStartSeq += acc < left ? acc : (left > 0 ? left : 0);
+        } else if (gStartSeq < c.startMax) {
+          // peers without room are tried (and flagged) until one accepts
+          int wIdx = mRoom ? (__ffs((int)mRoom) - 1) : NONE;
+          if (cand && peer <= wIdx) {
+            u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)gStartSeq);
+            const int at = start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
+            if (at >= 0) RING_PUSH(at, r.term, cmd);
+          }
+          if (mRoom) gStartSeq++;
+          (void)mAll;
+        }
+        storesPending = true;
+      }
+    }
+
+    STAMP(0);
+    // ------------------------------------------------------------ 2. actors
+    {
+      const bool live = valid && !r.has(F_DEAD);
+      const bool elDue = live && r.elNext <= now;
+      const bool monDue = live && r.has(F_MONALIVE) && r.monNext <= now;
+      int start = 0, myPos = 0;
+      bool pend = false, specEl = false, specMon = false, pendLocal = false;
+      if (elDue) {
+        int st = r.state();
+        if (st == RG_FOLLOWER) {
+          if (now - r.timer > r.timeout) { pend = true; pendLocal = true; }
+          else r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);   // nothing later in this tick can make it fire
+        } else if (st == RG_CANDIDATE) pend = true;
+        else specEl = true;
+      }
+      if (monDue) {
+        if (!r.isLeader()) {
+          if (r.state() == RG_CANDIDATE) pend = true;      // its own round may win first
+          else { r.flags &= ~F_MONALIVE; r.monNext = 0; }  // raft.go:526-528
+        } else {
+          int since = now - r.hbTimer;
+          bool gate = r.has(F_FIRST) || since >= RG_HB_IDLE_MS || (r.commit < r.logLen - 1 && since >= RG_HB_BACKLOG_MS);
+          if (gate || r.has(F_CDIRTY)) pend = true; else specMon = true;
+        }
+      }
+      if (pend) { specEl = false; specMon = false; }
+      // A timed-out follower only turns candidate (raft.go:557-562): no RPC.  When no peer of its group can run a
+      // round in this tick nothing can reach it before its turn, so it need not wait for it.
+      if (wave_any(pendLocal)) {
+        const bool grpRound = G.ballot(pend && !pendLocal) != 0;
+        if (pendLocal && !grpRound) {
+          r.setState(RG_CANDIDATE);
+          r.timeout = next_random(r, key, peer);
+          ctr_add(w, RG_C_TIMEOUTS, 1);
+          r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);
+          pend = false;
+        }
+      }
+      STAMP(1);
+      if (wave_any(pend)) { start = turn_start(key, t, P); myPos = peer - start + (peer < start ? P : 0); }
+
+      while (wave_any(pend)) {
+        SECTION_COUNT(w, 0);
+        chkLeaders = true;
+        const unsigned pm = G.ballot(pend);
+        const unsigned pmHi = pm >> start;                   // cyclic order from this tick's start
+        const int s = pmHi ? (start + __ffs((int)pmHi) - 1) : (pm ? (__ffs((int)pm) - 1) : -1);   // this group's acting peer
+        const int sPos = s - start + (s < start ? P : 0);
+        const bool isS = pend && peer == s;
+        const int sIdx = s < 0 ? 0 : s;
+        // ---------------- election loop iteration, raft.go:548-668
+        bool wantRV = false;
+        if (isS && r.elNext <= now) {
+          int st = r.state();
+          if (st == RG_FOLLOWER) {
+            if (now - r.timer > r.timeout) {
+              r.setState(RG_CANDIDATE);
+              r.timeout = next_random(r, key, peer);
+              ctr_add(w, RG_C_TIMEOUTS, 1);
+            }
+            r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);
+          } else if (st == RG_CANDIDATE) {
+            wantRV = true;
+          } else {
+            r.elNext = now + RG_ELECTION_PERIOD_MS + RG_ELECTION_LEADER_EXTRA_MS + sleep_slack(key, peer, now);
+          }
+        }
+        STAMP(5);
+        if (wave_any(wantRV)) {
+          SECTION_COUNT(w, 1);
+          // candidate prologue, raft.go:566-590
+          int aLli = 0, aLlt = 0;
+          if (wantRV) {
+            r.timeout = RG_CANDIDATE_WINDOW_MS;
+            r.timer = now;
+            if (!r.has(F_RESTART)) r.term++; else r.flags &= ~F_RESTART;
+            r.vote = peer;
+            persist(r, L, w);
+            aLli = r.commit;
+            aLlt = r.cTerm;                                  // logs[commitIndex].Term, raft.go:583
+            persist(r, L, w);
+            ctr_add(w, RG_C_RV_ROUNDS, 1);
+          }
+          const bool inR = G.ballot(wantRV) != 0;
+          const int T = G.shfl(r.term, sIdx), lli = G.shfl(aLli, sIdx), llt = G.shfl(aLlt, sIdx);
+          const unsigned seq = (unsigned)r.cold[CD_ROUNDSEQ * 256 + (sIdx - peer)];   // the sender's word, read in place
+          const unsigned fS = G.shflu(r.flags, sIdx);
+          if (wantRV) r.cd(CD_ROUNDSEQ) = (int)(seq + 1u);
+          const bool tgt = inR && valid && peer != s;
+          const bool reach = tgt && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
+          const u64 delays = round_delays(c, key, sIdx, seq);
+          const int outW = tgt ? net_outcome(c, key, reach, s, peer, seq, delays) : 0;
+          const int out = outW & 3;
+          VoteDecision d; d.rTerm = 0; d.touch = d.raise = d.grant = false;
+          if (out != 0) d = decide_vote(r, r.cTerm, T, s, lli, llt);
+          const unsigned sdm = G.ballot(out == 2 && d.rTerm > T);      // raft.go:622
+          const int b = sdm ? (__ffs((int)sdm) - 1) : NONE;
+          const bool called = tgt && peer <= b, ran = out != 0 && peer <= b, ok = out == 2 && peer <= b;
+          if (ran) {
+            const bool wasLead = r.state() == RG_LEADER;
+            commit_vote(r, d, T, s, now, lg, sn, peer, L, w);
+            if (wasLead && d.touch && myPos > sPos && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
+          }
+          const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok), grantM = G.ballot(ok && d.grant);
+          if constexpr (BYTES) atomicAdd((unsigned *)&coldLds[CD_N + 2][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
+          const int busy = round_busy<P>(calledM, okM, delays);
+          bool won = false;
+          if (wantRV) {
+            ctr_add(w, RG_C_RPC_SENT, (unsigned)__popc(calledM));
+            ctr_add(w, RG_C_RPC_DELIVERED, (unsigned)__popc(ranM));
+            ctr_add(w, RG_C_RPC_REPLIED, (unsigned)__popc(okM));
+            int voteCnt = 1 + __popc(grantM);
+            if (b < NONE) {                                          // raft.go:622-627: term is not adopted
+              r.setState(RG_FOLLOWER);
+              r.vote = -1;
+              persist(r, L, w);
+              ctr_add(w, RG_C_STEPDOWNS, 1);
+              r.timeout = next_random(r, key, peer);                // raft.go:639
+            } else if (2 * voteCnt > P) {                          // raft.go:641-658
+              won = true;
+              r.flags &= ~(F_STOP | F_CNT_MASK);
+              r.setState(RG_LEADER);
+              r.hbTimer = now + busy;
+              r.flags |= F_MONALIVE | F_FIRST | F_CDIRTY;
+              r.monNext = now + busy;
+              int f = r.logLen;
+              if (r.lastTerm == r.term) { while (f > 0 && *lg.termp(f - 1, peer) == r.term) f--; }
+              r.firstOwn = f;
+              ctr_add(w, RG_C_ELECTIONS_WON, 1);
+            } else {
+              r.flags |= F_RESTART;
+            }
+            r.elNext = now + busy + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);
+          }
+          const bool grpWon = G.ballot(won) != 0;
+          int lenW = 0;
+          if (wave_any(won)) lenW = G.shfl(r.logLen, sIdx);
+          if (grpWon && valid) { nextRow(sIdx * PP + peer) = lenW; matchRow(sIdx * PP + peer) = 0; cOwner = s; cNext = lenW; cMatch = 0; }
+          if (wave_any(grpWon)) storesPending = true;
+        }
+        STAMP(6);
+        // ---------------- leader loop, raft.go:395-529, until it sleeps or exits
+        bool monAct = isS && r.has(F_MONALIVE) && r.monNext <= now;
+        for (;;) {
+          bool wantAE = false;
+          // commit rule, raft.go:400-416, in closed form: the largest N held by a majority is the floor(P/2)-th
+          // largest follower matchIndex.  Each follower ranks its own value against the others' (from its cache
+          // of this leader's row, filled from memory on a miss) and the group maximum of the qualifying values
+          // is N.  The loop of the reference reaches N only if every entry from N up carries the current term:
+          // N >= firstOwn.
+          int Nstar = 0;
+          const bool needCR = monAct && r.isLeader() && r.has(F_CDIRTY);
+          if (wave_any(needCR)) {
+            const bool fol = G.ballot(needCR) != 0 && valid && peer != s;
+            if (wave_any(fol && cOwner != s)) {
+              SYNC_STORES();
+              if (fol && cOwner != s) { cNext = nextRow(sIdx * PP + peer); cMatch = matchRow(sIdx * PP + peer); cOwner = s; WAIT_LOADS(); }
+            }
+            const int mv = fol ? cMatch : -1;
+            int ge = 0;
+#pragma unroll
+            for (int u = 0; u < P; u++) ge += G.shfl(mv, u) >= mv ? 1 : 0;
+            Nstar = G.gmax((fol && ge >= P / 2) ? mv : 0);
+          }
+          if (monAct) {
+            if (!r.isLeader()) { r.flags &= ~F_MONALIVE; r.monNext = 0; monAct = false; }
+            else {
+              if (r.has(F_CDIRTY)) {
+                r.flags &= ~F_CDIRTY;
+                int N = Nstar;
+                if (N > r.logLen - 1) N = r.logLen - 1;
+                if (N > r.commit && N >= r.firstOwn) {
+                  ctr_add(w, RG_C_ENTRIES_COMMITTED, (unsigned)(N - r.commit));
+                  r.commit = N;
+                  r.cTerm = r.term;                                  // N >= firstOwn
+                  r.flags |= F_FIRST;
+                  persist(r, L, w);
+                }
+              }
+              int since = now - r.hbTimer;
+              if (r.has(F_FIRST) || since >= RG_HB_IDLE_MS || (r.commit < r.logLen - 1 && since >= RG_HB_BACKLOG_MS)) {
+                r.flags &= ~F_FIRST;
+                wantAE = true;
+                ctr_add(w, RG_C_AE_ROUNDS, 1);
+              } else {
+                r.monNext = now + RG_MONITOR_POLL_MS;
+                monAct = false;
+              }
+            }
+          }
+          SECTION_COUNT(w, 2);
+          STAMP(7);
+          if (!wave_any(wantAE)) break;
+          SECTION_COUNT(w, 3);
+          // ---------------- one replication round, raft.go:423-512
+          const bool inR = G.ballot(wantAE) != 0;
+          const int T = G.shfl(r.term, sIdx), lenS = G.shfl(r.logLen, sIdx), commitS = G.shfl(r.commit, sIdx);
+          const int lastTermS = G.shfl(r.lastTerm, sIdx), firstOwnS = G.shfl(r.firstOwn, sIdx), cTermS = G.shfl(r.cTerm, sIdx);
+          const unsigned seq = (unsigned)r.cold[CD_ROUNDSEQ * 256 + (sIdx - peer)];
+          const unsigned fS = G.shflu(r.flags, sIdx);
+          if (wantAE) r.cd(CD_ROUNDSEQ) = (int)(seq + 1u);
+          const bool tgt = inR && valid && peer != s;
+          if (wave_any(tgt && cOwner != s)) {
+            SECTION_COUNT(w, 8);
+            SYNC_STORES();
+            if (tgt && cOwner != s) { cNext = nextRow(sIdx * PP + peer); cMatch = matchRow(sIdx * PP + peer); cOwner = s; WAIT_LOADS(); }
+          }
+          const int nx = tgt ? cNext : 0;
+          const unsigned ovm = G.ballot(tgt && nx > lenS);           // raft.go:451-454 ends the round
+          const int firstOv = ovm ? (__ffs((int)ovm) - 1) : NONE;
+          const bool tgt2 = tgt && peer < firstOv;
+          const bool reach = tgt2 && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
+          const u64 delays = round_delays(c, key, sIdx, seq);
+          const int outW = tgt2 ? net_outcome(c, key, reach, s, peer, seq, delays) : 0;
+          const int out = outW & 3;
+          const int prev = nx - 1, k = lenS - nx;
+          AppendDecision d; d.rTerm = 0; d.ct = 0; d.ci = 0; d.touch = d.match = false;
+          int prevTerm = 0;
+          const int sTid = tid - peer + sIdx;                        // the sender's lane in the block
+          // logs[Prev].Term on both sides: from the lanes' caches, else from the rings, else from HBM
+          int myPrevTerm = -2;
+          bool needS = false, needM = false;
+          if (out != 0) {
+            prevTerm = prev == lenS - 1 ? lastTermS : T;
+            needS = prev != lenS - 1 && prev < firstOwnS;
+            if (prev == r.logLen - 1) myPrevTerm = r.lastTerm; else needM = prev < r.logLen - 1;
+            const int pq = prev & (RING - 1);
+            if (needS && ringIdx[pq][sTid] == prev) { prevTerm = ringTerm[pq][sTid]; needS = false; }
+            if (needM && ringIdx[pq][tid] == prev) { myPrevTerm = ringTerm[pq][tid]; needM = false; }
+          }
+          if (wave_any(needS || needM)) {
+            SECTION_COUNT(w, 9);
+            SYNC_STORES();
+            if (needS || needM) {
+              if (needS) prevTerm = *lg.termp(prev, sIdx);
+              if (needM) myPrevTerm = *lg.termp(prev, peer);
+              WAIT_LOADS();
+            }
+          }
+          if (out != 0) d = decide_append(r, lg, peer, T, prev, prevTerm, myPrevTerm);
+          const unsigned sdm = G.ballot(out == 2 && d.rTerm > T);    // raft.go:482
+          const int b = sdm ? (__ffs((int)sdm) - 1) : NONE;
+          const bool called = tgt2 && peer <= b, ran = out != 0 && peer <= b, ok = out == 2 && peer <= b;
+          // Entries the sender wrote recently are copied from its ring.  A longer or older run (a follower catching
+          // up) is copied by the whole wave, one row per lane, so that its cost is one trip to HBM whatever its length.
+          bool viaHbm = false;
+          if (ran && d.touch && d.match && k > 0) {
+            viaHbm = k > RING;
+#pragma unroll
+            for (int q = 0; q < RING; q++) {               // slot q would hold the one index of nx..nx+3 that is q mod RING
+              const int want = nx + ((q - nx) & (RING - 1));
+              if (want < lenS && ringIdx[q][sTid] != want) viaHbm = true;
+            }
+          }
+          {
+            u64 hm = __builtin_amdgcn_ballot_w64(viaHbm);
+            const bool scan = ok && b != peer && d.touch && !d.match;
+            if (hm) SECTION_COUNT(w, 10);
+            if (wave_any(scan)) SECTION_COUNT(w, 11);
+            if (hm || wave_any(scan)) SYNC_STORES();
+            while (hm) {
+              const int src = (int)__builtin_ctzll(hm);
+              hm &= hm - 1;
+              const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src);
+              const int nxB = __builtin_amdgcn_readlane(nx, src), lenB = __builtin_amdgcn_readlane(lenS, src);
+              const unsigned sCol = (unsigned)__builtin_amdgcn_readlane(sIdx, src), tCol = (unsigned)__builtin_amdgcn_readlane(peer, src);
+              const int tTid = (tid & ~63) + src;
+              for (int i = nxB + G.lane; i < lenB; i += 64) {
+                char *row = lg.base + (size_t)(offB + (unsigned)i * (unsigned)lg.rowBytes);
+                const int tm = *(int *)(row + sCol * 4u);
+                const u64 cm = *(u64 *)(row + (unsigned)lg.cmdOff + sCol * 8u);
+                *(int *)(row + tCol * 4u) = tm;
+                *(u64 *)(row + (unsigned)lg.cmdOff + tCol * 8u) = cm;
+                if (i >= lenB - RING) { const int q = i & (RING - 1); ringIdx[q][tTid] = i; ringTerm[q][tTid] = tm; ringCmd[q][tTid] = cm; }
+              }
+            }
+          }
+          if (ran && d.touch) {
+            const bool wasLead = r.state() == RG_LEADER;
+            r.setState(RG_FOLLOWER);
+            r.vote = s;                                              // raft.go:281
+            if (r.term < T) { r.term = T; persist(r, L, w); }
+            r.timer = now;
+            if (d.match) {
+              if (!viaHbm) {
+                for (int i = nx; i < lenS; i++) {                    // at most RING entries, all in the sender's ring
+                  const int q = i & (RING - 1);
+                  const int tm = ringTerm[q][sTid]; const u64 cm = ringCmd[q][sTid];
+                  *lg.termp(i, peer) = tm; *lg.cmdp(i, peer) = cm;
+                  RING_PUSH(i, tm, cm);
+                }
+              }
+              if (k > 0 && nx < r.snapSync) r.snapSync = nx;
+              r.logLen = lenS;
+              r.lastTerm = k > 0 ? lastTermS : prevTerm;
+              const int oldCommit = r.commit;
+              if (commitS > r.commit) r.commit = (r.logLen - 1 < commitS) ? r.logLen - 1 : commitS;
+              if (r.commit > r.logLen - 1) gfl |= RG_FLAG_REF_PANIC;
+              if (r.commit != oldCommit || nx <= r.commit) {          // the entry at commitIndex is new or was rewritten
+                if (r.commit == lenS - 1) r.cTerm = r.lastTerm;
+                else if (r.commit == commitS && commitS < lenS) r.cTerm = cTermS;
+                else { wave_fence(); r.cTerm = *lg.termp(r.commit < L ? r.commit : L - 1, peer); WAIT_LOADS(); }
+              }
+              persist(r, L, w);
+              ctr_add(w, RG_C_ENTRIES_REPLICATED, (unsigned)k);
+            } else {
+              ctr_add(w, RG_C_AE_CONFLICTS, 1);
+            }
+            if (wasLead && myPos > sPos && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
+          }
+          // the leader's handling of each reply, done by the replying lane
+          if (ok && b != peer) {
+            if (d.match) { cNext = lenS; cMatch = lenS - 1; matchRow(sIdx * PP + peer) = cMatch; }
+            else cNext = leader_backoff(lg, sIdx, nx, d.ct, d.ci);   // a stale-term reply would have ended the round
+            nextRow(sIdx * PP + peer) = cNext;
+          }
+          const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
+          if constexpr (BYTES) {   // wire bytes: summed per target lane in LDS words of its own, added to the counters when the launch ends
+            atomicAdd((unsigned *)&coldLds[CD_N + 2][tid], called ? (unsigned)RG_APPEND_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_APPEND_REPLY_BYTES : 0u) : 0u);
+            atomicAdd((unsigned *)&coldLds[CD_N + 3][tid], (called && k > 0) ? (unsigned)k : 0u);
+          }
+          const int busy = round_busy<P>(calledM, okM, delays);
+          int rTermB = 0;
+          if (wave_any(b < NONE)) rTermB = G.shfl(d.rTerm, b < NONE ? b : 0);
+          if (wantAE) {
+            ctr_add(w, RG_C_RPC_SENT, (unsigned)__popc(calledM));
+            ctr_add(w, RG_C_RPC_DELIVERED, (unsigned)__popc(ranM));
+            ctr_add(w, RG_C_RPC_REPLIED, (unsigned)__popc(okM));
+            ctr_add(w, RG_C_AE_DELIVERED, (unsigned)__popc(ranM));
+            if (b < NONE) {                                            // raft.go:482-487: voteFor is kept
+              r.setState(RG_FOLLOWER);
+              r.term = rTermB;
+              persist(r, L, w);
+              ctr_add(w, RG_C_STEPDOWNS, 1);
+            }
+            int active = 1 + __popc(okM);
+            if (active == 1 && r.cnt() <= 3) {                       // raft.go:514-520
+              int cn = r.cnt() + 1;
+              r.setCnt(cn);
+              if (cn > 3) r.flags |= F_STOP;
+            }
+            r.hbTimer = now + busy;                                  // raft.go:521
+            r.flags |= F_CDIRTY;
+            if (busy > 0) { r.monNext = now + busy; monAct = false; }   // the loop goes on once the waits are over
+          }
+          storesPending = true;
+          STAMP(8);
+        }
+        if (isS) pend = false;
+      }
+      if (specEl) r.elNext = now + RG_ELECTION_PERIOD_MS + RG_ELECTION_LEADER_EXTRA_MS + sleep_slack(key, peer, now);
+      if (specMon) r.monNext = now + RG_MONITOR_POLL_MS;
+    }
+
+    STAMP(2);
+    // ------------------------------------------------------------ 3. apply, raft.go:676-686 + config.go:170-194
+    // The reference's tester sees peers 0..P-1 deliver in turn: peer p checks its entries up to the newest index
+    // recorded before its turn (pm = the larger of the record's end and the commitIndex of every lower peer)
+    // against the record, and records the rest.  Ranges of different peers that are recorded never overlap and the
+    // digest is a sum, so all peers record first and then all peers check, each range in one go.
+    {
+      const bool act = valid && !r.has(F_DEAD) && r.commit > r.applied;
+      if (wave_any(act)) {
+        SECTION_COUNT(w, 4);
+        const int cA = act ? r.commit : 0;
+        int pm = recMax, newMax = recMax;
+        if (wave_any(cA > recMax)) {
+#pragma unroll
+          for (int u = 0; u < P; u++) {
+            const int v = G.shfl(cA, u);
+            if (u < peer) pm = v > pm ? v : pm;
+            newMax = v > newMax ? v : newMax;
+          }
+        }
+        const int cmpHi = cA < pm ? cA : pm;
+        const int nCmp = (act && cmpHi > r.applied) ? cmpHi - r.applied : 0;       // checks (applied, cmpHi]
+        const int recLo = r.applied > pm ? r.applied : pm;
+        const int nRec = (act && r.commit > recLo) ? r.commit - recLo : 0;         // records (recLo, commit]
+        if (nRec > 0 && r.applied > pm) gfl |= RG_FLAG_APPLY_ORDER;                // config.go:184-187
+        if (act && r.commit >= r.logLen) gfl |= RG_FLAG_REF_PANIC;                 // raft.go:679 would index past the log
+        unsigned accLo = 0, accHi = 0;
+        bool bad = false;
+        // ---- record
+        if (wave_any(nRec > 0)) {
+          bool slow = nRec > RING;
+#pragma unroll
+          for (int q = 0; q < RING; q++) {
+            const int want = recLo + 1 + ((q - recLo - 1) & (RING - 1));
+            if (want <= r.commit && nRec > 0 && ringIdx[q][tid] != want) slow = true;
+          }
+          u64 sm = __builtin_amdgcn_ballot_w64(slow);
+          if (nRec > 0 && !slow) {
+            for (int j = 0; j < nRec; j++) {
+              const int i = recLo + 1 + j, q = i & (RING - 1);
+              const u64 cmd = ringCmd[q][tid];
+              rec(i < L ? i : L - 1) = cmd;
+              if (i > newMax - RING) { recIdx[q][gLoc] = i; recVal[q][gLoc] = cmd; }
+              const u64 wd = apply_word(cmd, i);
+              accLo += (unsigned)wd; accHi += (unsigned)(wd >> 32);
+            }
+          }
+          if (sm) {                                   // long or old runs: the whole wave, one entry per lane
+            SECTION_COUNT(w, 13);
+            SYNC_STORES();
+            do {
+              const int src = (int)__builtin_ctzll(sm);
+              sm &= sm - 1;
+              const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), rOffB = (unsigned)__builtin_amdgcn_readlane((int)rOff, src);
+              const int lo = __builtin_amdgcn_readlane(recLo, src), n = __builtin_amdgcn_readlane(nRec, src);
+              const int top = __builtin_amdgcn_readlane(newMax, src), gSrc = __builtin_amdgcn_readlane((int)gLoc, src);
+              const unsigned col = (unsigned)__builtin_amdgcn_readlane(peer, src);
+              const int tTid = (tid & ~63) + src;
+              for (int j = G.lane; j < n; j += 64) {
+                const int i = lo + 1 + j, ic = i < L ? i : L - 1, q = i & (RING - 1);
+                const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
+                recBlk[rOffB + (unsigned)ic] = cmd;
+                if (i > top - RING) { recIdx[q][gSrc] = i; recVal[q][gSrc] = cmd; }
+                const u64 wd = apply_word(cmd, i);
+                atomicAdd((unsigned *)&coldLds[CD_AH_LO][tTid], (unsigned)wd);
+                atomicAdd((unsigned *)&coldLds[CD_AH_HI][tTid], (unsigned)(wd >> 32));
+              }
+            } while (sm);
+          }
+          recMax = newMax;
+          storesPending = true;
+        }
+        // ---- check
+        if (wave_any(nCmp > 0)) {
+          bool slow = nCmp > RING;
+#pragma unroll
+          for (int q = 0; q < RING; q++) {
+            const int want = r.applied + 1 + ((q - r.applied - 1) & (RING - 1));
+            if (want <= cmpHi && nCmp > 0 && !(ringIdx[q][tid] == want && recIdx[q][gLoc] == want)) slow = true;
+          }
+          u64 sm = __builtin_amdgcn_ballot_w64(slow);
+          if (nCmp > 0 && !slow) {
+            for (int j = 0; j < nCmp; j++) {
+              const int i = r.applied + 1 + j, q = i & (RING - 1);
+              const u64 cmd = ringCmd[q][tid];
+              bad |= cmd != recVal[q][gLoc];
+              const u64 wd = apply_word(cmd, i);
+              accLo += (unsigned)wd; accHi += (unsigned)(wd >> 32);
+            }
+          }
+          if (sm) {
+            SECTION_COUNT(w, 12);
+            SYNC_STORES();
+            do {
+              const int src = (int)__builtin_ctzll(sm);
+              sm &= sm - 1;
+              const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), rOffB = (unsigned)__builtin_amdgcn_readlane((int)rOff, src);
+              const int a = __builtin_amdgcn_readlane(r.applied, src), n = __builtin_amdgcn_readlane(nCmp, src);
+              const unsigned col = (unsigned)__builtin_amdgcn_readlane(peer, src);
+              const int tTid = (tid & ~63) + src;
+              bool differs = false;
+              for (int j = G.lane; j < n; j += 64) {
+                const int i = a + 1 + j, ic = i < L ? i : L - 1;
+                const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
+                const u64 seen = recBlk[rOffB + (unsigned)ic];
+                differs |= cmd != seen;
+                const u64 wd = apply_word(cmd, i);
+                atomicAdd((unsigned *)&coldLds[CD_AH_LO][tTid], (unsigned)wd);
+                atomicAdd((unsigned *)&coldLds[CD_AH_HI][tTid], (unsigned)(wd >> 32));
+              }
+              if (wave_any(differs) && G.lane == src) bad = true;
+            } while (sm);
+          }
+        }
+        if (act) {
+          if (bad) gfl |= RG_FLAG_STATE_MACHINE;
+          ctr_add(w, RG_C_ENTRIES_APPLIED, (unsigned)(r.commit - r.applied));
+          r.applied = r.commit;
+          atomicAdd((unsigned *)&coldLds[CD_AH_LO][tid], accLo);
+          atomicAdd((unsigned *)&coldLds[CD_AH_HI][tid], accHi);
+        }
+      }
+    }
+
+    STAMP(3);
+    // ------------------------------------------------------------ 4. one leader per term, config.go:307-320
+    {
+      const bool lead = chkLeaders && valid && r.has(F_CONNECTED) && r.isLeader();
+      const unsigned lm = G.ballot(lead);
+      chkLeaders = false;
+      if (wave_any(lead && __popc(lm) > 1)) {
+        SECTION_COUNT(w, 6);
+#pragma unroll
+        for (int u = 0; u < P; u++) {
+          int tu = G.shfl(r.term, u);
+          if (lead && u != peer && ((lm >> u) & 1u) && tu == r.term) gfl |= RG_FLAG_ELECTION_SAFETY;
+        }
+      }
+    }
+    STAMP(4);
+  }
+
+#undef SYNC_STORES
+#undef RING_PUSH
+  const int startSeqOut = gStartSeq, partEpochOut = gPartEpoch;
+  if constexpr (BYTES) {
+    if (coldLds[CD_N + 2][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 2][threadIdx.x]);
+    if (coldLds[CD_N + 3][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 3][threadIdx.x]);
+  }
+#undef gStartSeq
+#undef gPartEpoch
+#undef nextRow
+#undef matchRow
+#undef rec
+  if (G.inWave) r.store(*Sp, gl);
+  gfl = G.gor(gfl);
+  if (valid && peer == 0) {
+    Sp->startSeq[g] = startSeqOut; Sp->partNext[g] = partNext; Sp->partEpoch[g] = partEpochOut; Sp->recMax[g] = recMax;
+    if (gfl) Sp->gflags[g] |= gfl;
+  }
+  __syncthreads();
+  if (G.lane < RG_CTR_SLOTS && w->c[G.lane]) atomicAdd((unsigned long long *)&Sp->counters[G.lane], (unsigned long long)w->c[G.lane]);
+}
+
+#endif
