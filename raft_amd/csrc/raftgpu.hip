@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -41,6 +42,8 @@ typedef unsigned long long u64;
 struct rg_engine {
   rg_config cfg;
   int G, P, L, PP, Gpad, gpb, rowBytes, cmdOff;
+  int slotWaves;        // wavefronts of the tick kernel the device holds at once
+  int tickBlocks;       // grid of the tick kernel (DevCfg::nbA blocks of gwA groups per wave, then blocks of gwB)
   long long nLanes;
   DevPtrs S;
   DevPtrs *dS;          // device copy of S: the tick kernel reads the cold pointers through it
@@ -116,6 +119,21 @@ static void fill_devcfg(rg_engine *e) {
   d.partPeriod = c.part_period; d.partJitter = c.part_jitter;
   d.churnPeriod = c.churn_period; d.churnDisc = c.churn_disconnect_permille; d.churnRestart = c.churn_restart_permille; d.churnCrash = c.churn_crash_permille;
   d.acctBytes = c.account_bytes != 0;
+  // Packing of groups into waves.  Whole batches that fill every wave slot use full waves (64/P groups).  A
+  // launch smaller than one batch is spread over all wave slots; what is left after whole batches is spread
+  // over half of them (measured on the 65,536 x 5 workload: 2 blocks per CU finish the remainder earliest,
+  // because it starts while the last whole batch is still draining).
+  const int gwMax = 64 / e->P;
+  const long long cap = (long long)e->slotWaves * gwMax;
+  const int fullBatches = (int)(e->G / cap);
+  d.gwA = gwMax; d.nbA = fullBatches * (e->slotWaves / 4);
+  if (const char *ov = getenv("RAFTGPU_FULL_BLOCKS")) { int v = atoi(ov); if (v >= 0 && (long long)v * 4 * gwMax <= e->G) d.nbA = v; }   // tuning aid
+  const int rest = e->G - d.nbA * 4 * gwMax;
+  const int spread = d.nbA > 0 ? e->slotWaves / 2 : e->slotWaves;
+  int gwB = (rest + spread - 1) / spread;
+  if (const char *ov = getenv("RAFTGPU_TAIL_GROUPS_PER_WAVE")) gwB = atoi(ov);   // tuning aid
+  d.gwB = gwB < 1 ? 1 : (gwB > gwMax ? gwMax : gwB);
+  e->tickBlocks = d.nbA + (rest + 4 * d.gwB - 1) / (4 * d.gwB);
 }
 
 // Make for every peer: device memsets plus a host-built image of the few non-zero words.
@@ -205,7 +223,8 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   e->cfg = *cfg; e->G = cfg->n_groups; e->P = cfg->n_peers; e->L = cfg->log_cap;
   e->PP = e->P <= 4 ? 4 : 8;
   e->gpb = 4 * (64 / e->P);          // groups per block of the tick kernel: 64/P whole groups per wave
-  e->Gpad = (e->G + e->gpb - 1) / e->gpb * e->gpb;
+  e->Gpad = (e->G + e->gpb - 1) / e->gpb * e->gpb + e->gpb;   // thinner waves reach up to one block past the last group
+  e->slotWaves = prop.multiProcessorCount * 4 * RG_TICK_WAVES;
   e->nLanes = (long long)e->Gpad * e->PP;
   e->cmdOff = (e->P * 4 + 7) & ~7;
   e->rowBytes = (e->cmdOff + e->P * 8 + 15) & ~15;
@@ -294,7 +313,7 @@ static int run_derive(rg_engine *e) {
 static int launch_ticks(rg_engine *e, int n_ticks) {
   hipEvent_t a, b;
   HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-  const int blocks = e->Gpad / e->gpb;
+  const int blocks = e->tickBlocks;
   HIPCHK(hipEventRecord(a, e->stream));
   const DevPtrs *dS = e->dS;
 #define TICK_LAUNCH(PEERS) do { \

@@ -29,6 +29,7 @@ struct DevCfg {
   int partPeriod, partJitter;
   int churnPeriod, churnDisc, churnRestart, churnCrash;
   int acctBytes;
+  int nbA, gwA, gwB;             // tick kernel: blocks [0, nbA) hold gwA groups per wave, the others gwB
 };
 
 // packed per-peer flag word

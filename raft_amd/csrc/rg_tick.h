@@ -40,19 +40,21 @@ struct Grp {
   }
 };
 
-// Dense variant for the tick kernel: a group's P peers sit in P adjacent lanes, 64/P whole groups per
-// wave (12 for P = 5) and the 64 % P tail lanes idle, instead of padding every group to a power of two.
+// Dense variant for the tick kernel: a group's P peers sit in P adjacent lanes, up to 64/P whole groups per
+// wave (12 for P = 5), instead of padding every group to a power of two.  A wave may be given fewer groups
+// (gw): the cost of a tick grows with the number of groups that share a wave, so when the groups of a launch
+// (or of its last, partial batch) do not fill the chip's wave slots they are spread over more, thinner waves.
 template <int P>
 struct GrpN {
-  static constexpr int GW = 64 / P;          // groups per wave
+  static constexpr int GWMAX = 64 / P;       // most groups a wave can hold
   int lane, base, peer;
   bool inWave;
-  __device__ GrpN() {
+  __device__ explicit GrpN(int gw) {
     lane = (int)(threadIdx.x & 63);
     const int q = lane / P;
     base = q * P;
     peer = lane - base;
-    inWave = q < GW;
+    inWave = q < gw;
   }
   __device__ int rot(int d) const { int x = peer + d; return base + (x >= P ? x - P : x); }
   __device__ int shfl(int v, int j) const { return __builtin_amdgcn_ds_bpermute((base + j) << 2, v); }
@@ -144,17 +146,19 @@ template <int P, bool BYTES>
 __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
   constexpr int PP = P <= 4 ? 4 : 8;        // stride of a group in the per-peer arrays and matrices in memory
   constexpr int NONE = 8;                   // "no such peer" for first-set-bit results
-  constexpr int GW = GrpN<P>::GW;
-  constexpr int GPB = 4 * GW;               // groups per 256-thread block
+  constexpr int GPB = 4 * GrpN<P>::GWMAX;   // most groups of a 256-thread block
   __shared__ WaveCtr sctr[4];
-  const GrpN<P> G;
+  // blocks [0, nbA) hold gwA groups per wave, the rest gwB
+  const bool classA = (int)blockIdx.x < c.nbA;
+  const int gw = classA ? c.gwA : c.gwB;
+  const GrpN<P> G(gw);
   const int wave = (int)(threadIdx.x >> 6);
   WaveCtr *w = &sctr[wave];
   if (G.lane < RG_CTR_SLOTS) w->c[G.lane] = 0;
   __syncthreads();
 
-  const int g0 = (int)blockIdx.x * GPB;                        // the block's first group: always < G
-  const int g = g0 + wave * GW + (G.lane / P);
+  const int g0 = classA ? (int)blockIdx.x * 4 * c.gwA : c.nbA * 4 * c.gwA + ((int)blockIdx.x - c.nbA) * 4 * c.gwB;   // the block's first group: always < G
+  const int g = g0 + wave * gw + (G.lane / P);
   const int peer = G.peer;
   const bool valid = G.inWave && g < c.G;
   const int L = c.L;
