@@ -14,7 +14,16 @@ e.step(T); e.sync()
 buf = (C.c_uint64 * 56)()
 e._lib.rg_debug_section_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 assert e._lib.rg_debug_section_counts(e._h, buf) == 0
-wt = ((G + 11) // 12) * T   # 12 five-peer groups per wave
+def tick_waves(G, slots=4096, gw_max=12):
+    """Waves of a five-peer launch under the engine's packing rule (fill_devcfg in raft_amd/csrc/raftgpu.hip)."""
+    full = G // (slots * gw_max) * slots
+    rest = G - full * gw_max
+    spread = slots // 2 if full else slots
+    gw = max(1, min(gw_max, -(-rest // spread)))
+    return full + -(-rest // gw)
+
+
+wt = tick_waves(G) * T
 names = ["control", "classify", "(rest of actors)", "apply", "leader check", "pend header+election", "RV section", "monitor eval", "AE section"]
 cnt = {"pend header+election": 0, "RV section": 1, "monitor eval": 2, "AE section": 3, "apply": 4}
 tot = sum(buf[40:49])
