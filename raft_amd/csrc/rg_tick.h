@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   u64 *const recBlk = H.applyRec + (size_t)g0 * L;
   const unsigned rOff = gLoc * (unsigned)L;
 #define rec(i) recBlk[rOff + (unsigned)(i)]
-  const u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
+  u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
   __shared__ int coldLds[CD_N + (BYTES ? 4 : 2)][256];    // + two group words, + two per-lane byte-accounting sums
   // The last RING entries each peer wrote to its log, and the last RING records of each group, staged in LDS:
@@ -225,6 +225,12 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   for (int t = t0; t < t0 + nticks; t++) {
     const int now = t * RG_TICK_MS;
     STAMP_INIT;
+    {   // Values derived from the key alone (hash partials of the seeded streams) are cheap to recompute where a
+        // rare event needs them; kept across ticks they only crowd the register file and get spilled.
+      unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
+      asm volatile("" : "+v"(klo), "+v"(khi));
+      key = ((u64)khi << 32) | klo;
+    }
     // ------------------------------------------------------------ 1. control
     if (c.partPeriod > 0 && wave_any(t == partNext)) chkLeaders = true;
     if (c.partPeriod > 0 && t == partNext) {
