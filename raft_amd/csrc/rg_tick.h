@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #define rec(i) recBlk[rOff + (unsigned)(i)]
   u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
-  __shared__ int coldLds[CD_N + (BYTES ? 4 : 2)][256];    // + two group words, + two per-lane byte-accounting sums
+  __shared__ int coldLds[CD_N + 5][256];    // + group words, per-lane byte-accounting sums, next client Start tick    // + two group words, + two per-lane byte-accounting sums
   // The last RING entries each peer wrote to its log, and the last RING records of each group, staged in LDS:
   // a follower copies a leader's fresh entries, and every peer applies its fresh entries, without a trip to
   // HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
@@ -209,20 +209,80 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   // stores to words another lane may read later are drained (vmcnt) only right before such a read
   bool storesPending = false;
 #define SYNC_STORES() do { if (storesPending) { SECTION_COUNT(w, 7); wave_fence(); storesPending = false; } } while (0)
-  bool chkLeaders = true;      // the one-leader check is re-evaluated only after something changed
-  int nextStartTick = 0x7fffffff, nextChurnTick = 0x7fffffff, churnIt = 0;
-  if (c.startPeriod > 0) {
-    nextStartTick = c.startFirst;
-    if (t0 > c.startFirst) nextStartTick += (t0 - c.startFirst + c.startPeriod - 1) / c.startPeriod * c.startPeriod;
+  // Groups never exchange anything, so a wave need not keep its groups at the same tick.  Every group has its own
+  // clock tg: the next tick at which one of its peers or its control schedule has something to do.  One pass of
+  // the loop below advances every unfinished group of the wave through ITS next such tick; ticks in which a
+  // group has nothing to do are skipped for that group alone.  Wake-ups that provably change nothing but their
+  // own next wake-up time (a follower whose timer has not run out, a leader's election loop, a leader's monitor
+  // poll behind a closed gate) are not events: their chains are caught up when the group next runs a tick
+  // (catch_up) and once more when the launch ends, so every word is as the tick-by-tick order leaves it.
+  const int tEnd = t0 + nticks;
+#define MS_TICK(ms) (((ms) + (RG_TICK_MS - 1)) / RG_TICK_MS)    /* first tick whose time is >= ms (ms >= 0) */
+#define gNextStart coldLds[CD_N + 4][threadIdx.x]
+  {
+    int ns = 0x7fffffff;
+    if (c.startPeriod > 0) {
+      ns = c.startFirst;
+      if (t0 > c.startFirst) ns += (t0 - c.startFirst + c.startPeriod - 1) / c.startPeriod * c.startPeriod;
+    }
+    gNextStart = ns;
   }
-  if (c.churnPeriod > 0) {
-    int from = t0 > 1 ? t0 : 1;
-    churnIt = (from + c.churnPeriod - 1) / c.churnPeriod;
-    nextChurnTick = churnIt * c.churnPeriod;
-  }
+  // wake-ups of this lane that lie before tick T and change nothing else
+  auto catch_up = [&](int T) {
+    if (valid && !r.has(F_DEAD)) {
+      const int st = r.state();
+      if (st != RG_CANDIDATE) {                                   // a candidate's wake-ups are rounds: never skipped
+        const int extra = st == RG_LEADER ? RG_ELECTION_LEADER_EXTRA_MS : 0;
+        int tau = MS_TICK(r.elNext);
+        while (tau < T) {
+          const int ms = tau * RG_TICK_MS;
+          r.elNext = ms + RG_ELECTION_PERIOD_MS + extra + sleep_slack(key, peer, ms);
+          tau = MS_TICK(r.elNext);
+        }
+      }
+      if (r.has(F_MONALIVE) && r.isLeader()) {                    // polls behind a closed gate: every second tick
+        const int tau = MS_TICK(r.monNext);
+        if (tau < T) r.monNext = (tau + ((T - 1 - tau) & ~1)) * RG_TICK_MS + RG_MONITOR_POLL_MS;
+      }
+    }
+  };
+  // first tick >= from at which the lane's group has something to do
+  auto next_event = [&](int from) -> int {
+    int cand = 0x7fffffff;
+    if (valid && !r.has(F_DEAD)) {
+      const int st = r.state();
+      const int e = MS_TICK(r.elNext);
+      if (st == RG_CANDIDATE) cand = e;
+      else if (st == RG_FOLLOWER) {
+        const int fire = (r.timer + r.timeout) / RG_TICK_MS + 1;  // first tick with now - timer > timeout (raft.go:557)
+        cand = e > fire ? e : fire;                               // if the chain is behind, tick `fire` only catches it up
+      }
+      if (r.has(F_MONALIVE)) {
+        int m = MS_TICK(r.monNext);
+        if (r.isLeader() && !(r.flags & (F_FIRST | F_CDIRTY))) {  // gate of raft.go:421
+          const int open = MS_TICK(r.hbTimer + ((r.commit < r.logLen - 1) ? RG_HB_BACKLOG_MS : RG_HB_IDLE_MS));
+          if (open > m) m += ((open - m + 1) >> 1) << 1;
+        }
+        cand = m < cand ? m : cand;
+      }
+      if (r.commit > r.applied) cand = from;                      // entries committed by a host call are applied at once
+    }
+    cand = G.gmin(cand);
+    if (c.partPeriod > 0 && partNext < cand) cand = partNext;
+    if (c.startPeriod > 0 && gStartSeq < c.startMax && gNextStart < cand) cand = gNextStart;
+    if (c.churnPeriod > 0) {
+      const int nc = ((from > 1 ? from : 1) + c.churnPeriod - 1) / c.churnPeriod * c.churnPeriod;
+      if (nc < cand) cand = nc;
+    }
+    return cand > from ? cand : from;
+  };
 
   __builtin_amdgcn_s_waitcnt(0);         // nothing of the prologue is in flight when the loop starts
-  for (int t = t0; t < t0 + nticks; t++) {
+  int tg = next_event(t0);
+  if (!valid) tg = 0x7fffffff;
+  while (wave_any(tg < tEnd)) {
+    const bool run = tg < tEnd;            // the lane's group runs its tick tg in this pass
+    const int t = tg;
     const int now = t * RG_TICK_MS;
     STAMP_INIT;
     {   // Values derived from the key alone (hash partials of the seeded streams) are cheap to recompute where a
@@ -231,19 +291,19 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       asm volatile("" : "+v"(klo), "+v"(khi));
       key = ((u64)khi << 32) | klo;
     }
+    if (run) catch_up(t);
     // ------------------------------------------------------------ 1. control
-    if (c.partPeriod > 0 && wave_any(t == partNext)) chkLeaders = true;
-    if (c.partPeriod > 0 && t == partNext) {
+    if (c.partPeriod > 0 && run && t == partNext) {
       unsigned ep = (unsigned)gPartEpoch;
       r.set(F_SIDE, (stream_hash(key, STREAM_PART, ep, (unsigned)peer + 1) & 1) != 0);
       u64 h = stream_hash(key, STREAM_PART, ep, 0);
       partNext = t + c.partPeriod + (c.partJitter > 0 ? (int)(h % (u64)c.partJitter) : 0);
       gPartEpoch++;
     }
-    if (t == nextChurnTick) {                                        // test_test.go:893-919
-      unsigned it = (unsigned)churnIt;
-      churnIt++; nextChurnTick += c.churnPeriod;
-      chkLeaders = true; storesPending = true;
+    const bool churnNow = c.churnPeriod > 0 && run && t >= 1 && t % c.churnPeriod == 0;
+    if (c.churnPeriod > 0 && wave_any(churnNow)) storesPending = true;
+    if (churnNow) {                                                  // test_test.go:893-919
+      unsigned it = (unsigned)(t / c.churnPeriod);
       u64 h1 = stream_hash(key, STREAM_CHURN, it, 0), h2 = stream_hash(key, STREAM_CHURN, it, 1), h3 = stream_hash(key, STREAM_CHURN, it, 2);
       if ((int)((unsigned)(h1 & 0xFFFFF) % 1000u) < c.churnDisc && peer == (int)((h1 >> 32) % (u64)P)) r.flags &= ~F_CONNECTED;
       if ((int)((unsigned)(h2 & 0xFFFFF) % 1000u) < c.churnRestart && valid && peer == (int)((h2 >> 32) % (u64)P)) {
@@ -259,10 +319,11 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         r.flags |= F_DEAD;
       }
     }
-    if (t == nextStartTick) {
-      nextStartTick += c.startPeriod;
+    const bool startNow = c.startPeriod > 0 && run && t == gNextStart;
+    if (c.startPeriod > 0 && wave_any(startNow)) {
+      if (startNow) gNextStart += c.startPeriod;
       // client Starts: config.go:436-451 (first connected leader) / test_test.go:697-703 (every leader)
-      bool cand = valid && r.isLeader() && (c.startMode == RG_START_ALL || r.has(F_CONNECTED));
+      bool cand = startNow && valid && r.isLeader() && (c.startMode == RG_START_ALL || r.has(F_CONNECTED));
       if (wave_any(cand)) {
         SECTION_COUNT(w, 5);
         bool room = cand && r.logLen < L;
@@ -297,7 +358,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     STAMP(0);
     // ------------------------------------------------------------ 2. actors
     {
-      const bool live = valid && !r.has(F_DEAD);
+      const bool live = run && valid && !r.has(F_DEAD);
       const bool elDue = live && r.elNext <= now;
       const bool monDue = live && r.has(F_MONALIVE) && r.monNext <= now;
       int start = 0, myPos = 0;
@@ -338,7 +399,6 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 
       while (wave_any(pend)) {
         SECTION_COUNT(w, 0);
-        chkLeaders = true;
         const unsigned pm = G.ballot(pend);
         const unsigned pmHi = pm >> start;                   // cyclic order from this tick's start
         const int s = pmHi ? (start + __ffs((int)pmHi) - 1) : (pm ? (__ffs((int)pm) - 1) : -1);   // this group's acting peer
@@ -656,7 +716,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     // against the record, and records the rest.  Ranges of different peers that are recorded never overlap and the
     // digest is a sum, so all peers record first and then all peers check, each range in one go.
     {
-      const bool act = valid && !r.has(F_DEAD) && r.commit > r.applied;
+      const bool act = run && valid && !r.has(F_DEAD) && r.commit > r.applied;
       if (wave_any(act)) {
         SECTION_COUNT(w, 4);
         const int cA = act ? r.commit : 0;
@@ -776,9 +836,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     STAMP(3);
     // ------------------------------------------------------------ 4. one leader per term, config.go:307-320
     {
-      const bool lead = chkLeaders && valid && r.has(F_CONNECTED) && r.isLeader();
+      const bool lead = run && valid && r.has(F_CONNECTED) && r.isLeader();
       const unsigned lm = G.ballot(lead);
-      chkLeaders = false;
       if (wave_any(lead && __popc(lm) > 1)) {
         SECTION_COUNT(w, 6);
 #pragma unroll
@@ -789,7 +848,12 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       }
     }
     STAMP(4);
+    {   // this group's next tick with something to do
+      const int ne = next_event(t + 1);
+      if (run) tg = ne;
+    }
   }
+  catch_up(tEnd);                          // skipped wake-ups up to the end of the launch
 
 #undef SYNC_STORES
 #undef RING_PUSH
@@ -799,6 +863,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     if (coldLds[CD_N + 3][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 3][threadIdx.x]);
   }
 #undef gStartSeq
+#undef gNextStart
+#undef MS_TICK
 #undef gPartEpoch
 #undef nextRow
 #undef matchRow
