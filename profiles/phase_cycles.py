@@ -35,6 +35,7 @@ for i, n in enumerate(names):
     print("%-22s %8.1f cycles per wave-tick (%4.1f %%)%s" % (n, buf[40 + i] / wt, 100.0 * buf[40 + i] / tot, extra))
 print("total                  %8.1f cycles per wave-tick" % (tot / wt))
 extra = {7: "store fences", 8: "AE: matrix cache miss", 9: "AE: prevTerm from HBM", 10: "AE: entries from HBM", 11: "AE: backoff scan",
-         12: "apply: check by the wave", 13: "apply: record by the wave", 5: "Start", 6: "two-leader check"}
+         12: "apply: check by the wave", 13: "apply: record by the wave", 5: "Start", 6: "two-leader check",
+         14: "loop passes", 15: "group-ticks run (all groups of the wave)"}
 for k, n in extra.items():
     print("%-26s %.4f per wave-tick" % (n, buf[_abi.N_COUNTERS + k] / wt))

@@ -84,8 +84,10 @@ __device__ static inline void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ
 struct WaveCtr { unsigned c[RG_CTR_SLOTS]; };
 #ifdef RG_SECTION_COUNTS
 #define SECTION_COUNT(w, i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&(w)->c[RG_N_COUNTERS + (i)], 1u); } while (0)
+#define SECTION_COUNT_LANE(w, i) atomicAdd(&(w)->c[RG_N_COUNTERS + (i)], 1u)   /* once per calling lane */
 #else
 #define SECTION_COUNT(w, i) do { } while (0)
+#define SECTION_COUNT_LANE(w, i) do { } while (0)
 #endif
 #ifdef RG_STAMPS   // diagnostic builds only: shader cycles per phase of a tick, summed per wave into slots 40..
 #define STAMP(k) do { unsigned long long _n = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&w->c[40 + (k)], (unsigned)(_n - _stamp)); _stamp = _n; } while (0)

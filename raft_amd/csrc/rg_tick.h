@@ -248,8 +248,18 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   };
   // first tick >= from at which the lane's group has something to do
   auto next_event = [&](int from) -> int {
-    int cand = 0x7fffffff;
-    if (valid && !r.has(F_DEAD)) {
+    int cand = 0x7fffffff;       // this lane's next event
+    int candS = 0x7fffffff;      // the same if the pending client Start has been given to this lane first
+    const bool startOn = c.startPeriod > 0 && gStartSeq < c.startMax;
+    const int sTick = gNextStart;
+    const bool alive = valid && !r.has(F_DEAD);
+    // who takes the pending Start: every leader with room (test_test.go:697-703) or the first connected one (config.go:436-451)
+    bool taker = startOn && alive && r.isLeader() && r.logLen < L && (c.startMode == RG_START_ALL || r.has(F_CONNECTED));
+    if (c.startPeriod > 0 && c.startMode != RG_START_ALL) {
+      const unsigned tm = G.ballot(taker);
+      taker = taker && peer == __ffs((int)tm) - 1;
+    }
+    if (alive) {
       const int st = r.state();
       const int e = MS_TICK(r.elNext);
       if (st == RG_CANDIDATE) cand = e;
@@ -257,70 +267,47 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         const int fire = (r.timer + r.timeout) / RG_TICK_MS + 1;  // first tick with now - timer > timeout (raft.go:557)
         cand = e > fire ? e : fire;                               // if the chain is behind, tick `fire` only catches it up
       }
+      candS = cand;
       if (r.has(F_MONALIVE)) {
-        int m = MS_TICK(r.monNext);
-        if (r.isLeader() && !(r.flags & (F_FIRST | F_CDIRTY))) {  // gate of raft.go:421
+        const int m = MS_TICK(r.monNext);
+        int mGate = m, mStart = m;
+        if (r.isLeader() && !(r.flags & (F_FIRST | F_CDIRTY))) {  // gate of raft.go:421; polls come every second tick
           const int open = MS_TICK(r.hbTimer + ((r.commit < r.logLen - 1) ? RG_HB_BACKLOG_MS : RG_HB_IDLE_MS));
-          if (open > m) m += ((open - m + 1) >> 1) << 1;
+          if (open > m) mGate = m + (((open - m + 1) >> 1) << 1);
+          // with the Start's entry in the log from tick sTick on, the gate is the backlog one
+          int openS = MS_TICK(r.hbTimer + RG_HB_BACKLOG_MS);
+          openS = openS > sTick ? openS : sTick;
+          if (openS > m) mStart = m + (((openS - m + 1) >> 1) << 1);
+          if (!taker || mGate < mStart) mStart = mGate;
         }
-        cand = m < cand ? m : cand;
+        cand = mGate < cand ? mGate : cand;
+        candS = mStart < candS ? mStart : candS;
       }
-      if (r.commit > r.applied) cand = from;                      // entries committed by a host call are applied at once
+      if (r.commit > r.applied) { cand = from; candS = from; }   // entries committed by a host call are applied at once
     }
     cand = G.gmin(cand);
     if (c.partPeriod > 0 && partNext < cand) cand = partNext;
-    if (c.startPeriod > 0 && gStartSeq < c.startMax && gNextStart < cand) cand = gNextStart;
     if (c.churnPeriod > 0) {
       const int nc = ((from > 1 ? from : 1) + c.churnPeriod - 1) / c.churnPeriod * c.churnPeriod;
       if (nc < cand) cand = nc;
     }
+    if (c.startPeriod > 0 && wave_any(startOn && sTick < cand)) {
+      // The Start comes before anything else.  It changes no clock but its taker's gate, so it is not an event of its
+      // own: the group next runs when the taker's (earlier) poll passes the gate, at the Start after it at the latest.
+      candS = G.gmin(candS);
+      const int lim = sTick + c.startPeriod;
+      candS = candS < lim ? candS : lim;
+      if (startOn && sTick < cand) cand = candS < cand ? candS : cand;
+    }
     return cand > from ? cand : from;
   };
 
-  __builtin_amdgcn_s_waitcnt(0);         // nothing of the prologue is in flight when the loop starts
-  int tg = next_event(t0);
-  if (!valid) tg = 0x7fffffff;
-  while (wave_any(tg < tEnd)) {
-    const bool run = tg < tEnd;            // the lane's group runs its tick tg in this pass
-    const int t = tg;
-    const int now = t * RG_TICK_MS;
-    STAMP_INIT;
-    {   // Values derived from the key alone (hash partials of the seeded streams) are cheap to recompute where a
-        // rare event needs them; kept across ticks they only crowd the register file and get spilled.
-      unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
-      asm volatile("" : "+v"(klo), "+v"(khi));
-      key = ((u64)khi << 32) | klo;
-    }
-    if (run) catch_up(t);
-    // ------------------------------------------------------------ 1. control
-    if (c.partPeriod > 0 && run && t == partNext) {
-      unsigned ep = (unsigned)gPartEpoch;
-      r.set(F_SIDE, (stream_hash(key, STREAM_PART, ep, (unsigned)peer + 1) & 1) != 0);
-      u64 h = stream_hash(key, STREAM_PART, ep, 0);
-      partNext = t + c.partPeriod + (c.partJitter > 0 ? (int)(h % (u64)c.partJitter) : 0);
-      gPartEpoch++;
-    }
-    const bool churnNow = c.churnPeriod > 0 && run && t >= 1 && t % c.churnPeriod == 0;
-    if (c.churnPeriod > 0 && wave_any(churnNow)) storesPending = true;
-    if (churnNow) {                                                  // test_test.go:893-919
-      unsigned it = (unsigned)(t / c.churnPeriod);
-      u64 h1 = stream_hash(key, STREAM_CHURN, it, 0), h2 = stream_hash(key, STREAM_CHURN, it, 1), h3 = stream_hash(key, STREAM_CHURN, it, 2);
-      if ((int)((unsigned)(h1 & 0xFFFFF) % 1000u) < c.churnDisc && peer == (int)((h1 >> 32) % (u64)P)) r.flags &= ~F_CONNECTED;
-      if ((int)((unsigned)(h2 & 0xFFFFF) % 1000u) < c.churnRestart && valid && peer == (int)((h2 >> 32) % (u64)P)) {
-        if (r.has(F_DEAD)) {
-          make_peer(r, lg, sn, peer, L, key, now, w);
-#pragma unroll
-          for (int q = 0; q < RING; q++) ringIdx[q][tid] = -1;     // the log may have been rebuilt from an imported blob
-        }
-        r.flags |= F_CONNECTED;
-      }
-      if ((int)((unsigned)(h3 & 0xFFFFF) % 1000u) < c.churnCrash && peer == (int)((h3 >> 32) % (u64)P) && !r.has(F_DEAD)) {
-        r.flags &= ~F_CONNECTED;
-        r.flags |= F_DEAD;
-      }
-    }
-    const bool startNow = c.startPeriod > 0 && run && t == gNextStart;
-    if (c.startPeriod > 0 && wave_any(startNow)) {
+  // Client Starts of the lane's group that are due up to tick `upTo` (next_event lets a group skip the tick of a
+  // Start and accounts for what the Start changes; Start() itself does not look at the clock).
+  auto client_starts = [&](bool on, int upTo) {
+    for (;;) {
+      const bool startNow = c.startPeriod > 0 && on && gNextStart <= upTo && gStartSeq < c.startMax;
+      if (!(c.startPeriod > 0 && wave_any(startNow))) break;
       if (startNow) gNextStart += c.startPeriod;
       // client Starts: config.go:436-451 (first connected leader) / test_test.go:697-703 (every leader)
       bool cand = startNow && valid && r.isLeader() && (c.startMode == RG_START_ALL || r.has(F_CONNECTED));
@@ -354,6 +341,53 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         storesPending = true;
       }
     }
+  };
+
+  int tg = next_event(t0);
+  if (!valid) tg = 0x7fffffff;
+  while (wave_any(tg < tEnd)) {
+    const bool run = tg < tEnd;            // the lane's group runs its tick tg in this pass
+    SECTION_COUNT(w, 14);
+    if (wave_any(run && G.peer == 0)) { if (run && G.peer == 0 && G.inWave) SECTION_COUNT_LANE(w, 15); }
+    const int t = tg;
+    const int now = t * RG_TICK_MS;
+    STAMP_INIT;
+    {   // Values derived from the key alone (hash partials of the seeded streams) are cheap to recompute where a
+        // rare event needs them; kept across ticks they only crowd the register file and get spilled.
+      unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
+      asm volatile("" : "+v"(klo), "+v"(khi));
+      key = ((u64)khi << 32) | klo;
+    }
+    if (run) catch_up(t);
+    client_starts(run, t - 1);             // a Start of a tick the group skipped precedes this tick's control events
+    // ------------------------------------------------------------ 1. control
+    if (c.partPeriod > 0 && run && t == partNext) {
+      unsigned ep = (unsigned)gPartEpoch;
+      r.set(F_SIDE, (stream_hash(key, STREAM_PART, ep, (unsigned)peer + 1) & 1) != 0);
+      u64 h = stream_hash(key, STREAM_PART, ep, 0);
+      partNext = t + c.partPeriod + (c.partJitter > 0 ? (int)(h % (u64)c.partJitter) : 0);
+      gPartEpoch++;
+    }
+    const bool churnNow = c.churnPeriod > 0 && run && t >= 1 && t % c.churnPeriod == 0;
+    if (c.churnPeriod > 0 && wave_any(churnNow)) storesPending = true;
+    if (churnNow) {                                                  // test_test.go:893-919
+      unsigned it = (unsigned)(t / c.churnPeriod);
+      u64 h1 = stream_hash(key, STREAM_CHURN, it, 0), h2 = stream_hash(key, STREAM_CHURN, it, 1), h3 = stream_hash(key, STREAM_CHURN, it, 2);
+      if ((int)((unsigned)(h1 & 0xFFFFF) % 1000u) < c.churnDisc && peer == (int)((h1 >> 32) % (u64)P)) r.flags &= ~F_CONNECTED;
+      if ((int)((unsigned)(h2 & 0xFFFFF) % 1000u) < c.churnRestart && valid && peer == (int)((h2 >> 32) % (u64)P)) {
+        if (r.has(F_DEAD)) {
+          make_peer(r, lg, sn, peer, L, key, now, w);
+#pragma unroll
+          for (int q = 0; q < RING; q++) ringIdx[q][tid] = -1;     // the log may have been rebuilt from an imported blob
+        }
+        r.flags |= F_CONNECTED;
+      }
+      if ((int)((unsigned)(h3 & 0xFFFFF) % 1000u) < c.churnCrash && peer == (int)((h3 >> 32) % (u64)P) && !r.has(F_DEAD)) {
+        r.flags &= ~F_CONNECTED;
+        r.flags |= F_DEAD;
+      }
+    }
+    client_starts(run, t);
 
     STAMP(0);
     // ------------------------------------------------------------ 2. actors
@@ -853,7 +887,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       if (run) tg = ne;
     }
   }
-  catch_up(tEnd);                          // skipped wake-ups up to the end of the launch
+  client_starts(valid, tEnd - 1);          // Starts and wake-ups the groups skipped towards the end of the launch
+  catch_up(tEnd);
 
 #undef SYNC_STORES
 #undef RING_PUSH
