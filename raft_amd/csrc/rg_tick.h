@@ -359,16 +359,18 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       key = ((u64)khi << 32) | klo;
     }
     if (run) catch_up(t);
-    client_starts(run, t - 1);             // a Start of a tick the group skipped precedes this tick's control events
     // ------------------------------------------------------------ 1. control
-    if (c.partPeriod > 0 && run && t == partNext) {
+    const bool partNow = c.partPeriod > 0 && run && t == partNext;
+    const bool churnNow = c.churnPeriod > 0 && run && t >= 1 && t % c.churnPeriod == 0;
+    // a Start of a tick the group skipped precedes this tick's control events (otherwise one call below does both)
+    if ((c.partPeriod > 0 || c.churnPeriod > 0) && wave_any(partNow || churnNow)) client_starts(run, t - 1);
+    if (partNow) {
       unsigned ep = (unsigned)gPartEpoch;
       r.set(F_SIDE, (stream_hash(key, STREAM_PART, ep, (unsigned)peer + 1) & 1) != 0);
       u64 h = stream_hash(key, STREAM_PART, ep, 0);
       partNext = t + c.partPeriod + (c.partJitter > 0 ? (int)(h % (u64)c.partJitter) : 0);
       gPartEpoch++;
     }
-    const bool churnNow = c.churnPeriod > 0 && run && t >= 1 && t % c.churnPeriod == 0;
     if (c.churnPeriod > 0 && wave_any(churnNow)) storesPending = true;
     if (churnNow) {                                                  // test_test.go:893-919
       unsigned it = (unsigned)(t / c.churnPeriod);
