@@ -715,6 +715,20 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           const int busy = round_busy<P>(calledM, okM, delays);
           int rTermB = 0;
           if (wave_any(b < NONE)) rTermB = G.shfl(d.rTerm, b < NONE ? b : 0);
+          // Would the commit rule (raft.go:400-416) move commitIndex with the matchIndex row as this round leaves it?
+          // Nothing but the leader's next round changes the row, so if not, the evaluation that follows the round's
+          // waits finds nothing to do and need not wake the group.
+          int nAfter = 0;
+          bool ruleOpen = false;
+          {
+            const bool folR = inR && valid && peer != s;
+            ruleOpen = G.ballot(folR && cOwner != s) != 0;       // a follower the round did not reach: decided at the evaluation
+            const int mv = folR ? cMatch : -1;
+            int ge = 0;
+#pragma unroll
+            for (int u = 0; u < P; u++) ge += G.shfl(mv, u) >= mv ? 1 : 0;
+            nAfter = G.gmax((folR && ge >= P / 2) ? mv : 0);
+          }
           if (wantAE) {
             ctr_add(w, RG_C_RPC_SENT, (unsigned)__popc(calledM));
             ctr_add(w, RG_C_RPC_DELIVERED, (unsigned)__popc(ranM));
@@ -733,7 +747,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               if (cn > 3) r.flags |= F_STOP;
             }
             r.hbTimer = now + busy;                                  // raft.go:521
-            r.flags |= F_CDIRTY;
+            { int N = nAfter; if (N > r.logLen - 1) N = r.logLen - 1; if (ruleOpen || (N > r.commit && N >= r.firstOwn)) r.flags |= F_CDIRTY; }
             if (busy > 0) { r.monNext = now + busy; monAct = false; }   // the loop goes on once the waits are over
           }
           storesPending = true;
