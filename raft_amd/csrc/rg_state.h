@@ -97,15 +97,14 @@ struct WaveCtr { unsigned c[RG_CTR_SLOTS]; };
 #define STAMP_INIT do { } while (0)
 #endif
 
-enum { CD_SNAPTERM = 0, CD_SNAPVOTE, CD_SNAPLEN, CD_RNGCTR, CD_ROUNDSEQ, CD_AH_LO, CD_AH_HI, CD_N };
+enum { CD_SNAPTERM = 0, CD_SNAPVOTE, CD_SNAPLEN, CD_RNGCTR, CD_ROUNDSEQ, CD_AH_LO, CD_AH_HI, CD_APPLIED, CD_SNAPSYNC, CD_N };
 
 typedef __attribute__((address_space(3))) int lds_int;
 
 // Registers of one peer.  CP = type of the pointer to the event-only words (LDS rows or a local array).
 template <typename CP>
 struct LaneT {
-  int term, vote, commit, applied, logLen, timer, timeout, hbTimer, elNext, monNext;
-  int snapSync;
+  int term, vote, commit, logLen, timer, timeout, hbTimer, elNext, monNext;
   // caches of log words (rebuilt by k_derive after host writes): term of the last entry, first index from
   // which every entry carries the current term, term of the entry at commitIndex
   int lastTerm, firstOwn, cTerm;
@@ -128,17 +127,17 @@ struct LaneT {
   __device__ bool isLeader() const { return (flags & (F_DEAD | F_STOP | F_STATE_MASK)) == (unsigned)RG_LEADER; }
 
   __device__ void load(const DevPtrs &S, long long gl) {
-    term = S.term[gl]; vote = S.vote[gl]; flags = (unsigned)S.flags[gl]; commit = S.commit[gl]; applied = S.applied[gl];
+    term = S.term[gl]; vote = S.vote[gl]; flags = (unsigned)S.flags[gl]; commit = S.commit[gl]; cd(CD_APPLIED) = S.applied[gl];
     logLen = S.logLen[gl]; timer = S.timer[gl]; timeout = S.timeout[gl]; hbTimer = S.hbTimer[gl]; elNext = S.elNext[gl];
     monNext = S.monNext[gl]; cd(CD_RNGCTR) = S.rngCtr[gl]; cd(CD_ROUNDSEQ) = S.roundSeq[gl];
-    cd(CD_SNAPTERM) = S.snapTerm[gl]; cd(CD_SNAPVOTE) = S.snapVote[gl]; cd(CD_SNAPLEN) = S.snapLen[gl]; snapSync = S.snapSync[gl];
+    cd(CD_SNAPTERM) = S.snapTerm[gl]; cd(CD_SNAPVOTE) = S.snapVote[gl]; cd(CD_SNAPLEN) = S.snapLen[gl]; cd(CD_SNAPSYNC) = S.snapSync[gl];
     lastTerm = S.lastTerm[gl]; firstOwn = S.firstOwn[gl]; cTerm = S.commitTerm[gl]; setApplyHash(S.applyHash[gl]);
   }
   __device__ void store(const DevPtrs &S, long long gl) const {
-    S.term[gl] = term; S.vote[gl] = vote; S.flags[gl] = (int)flags; S.commit[gl] = commit; S.applied[gl] = applied;
+    S.term[gl] = term; S.vote[gl] = vote; S.flags[gl] = (int)flags; S.commit[gl] = commit; S.applied[gl] = cd(CD_APPLIED);
     S.logLen[gl] = logLen; S.timer[gl] = timer; S.timeout[gl] = timeout; S.hbTimer[gl] = hbTimer; S.elNext[gl] = elNext;
     S.monNext[gl] = monNext; S.rngCtr[gl] = cd(CD_RNGCTR); S.roundSeq[gl] = cd(CD_ROUNDSEQ);
-    S.snapTerm[gl] = cd(CD_SNAPTERM); S.snapVote[gl] = cd(CD_SNAPVOTE); S.snapLen[gl] = cd(CD_SNAPLEN); S.snapSync[gl] = snapSync;
+    S.snapTerm[gl] = cd(CD_SNAPTERM); S.snapVote[gl] = cd(CD_SNAPVOTE); S.snapLen[gl] = cd(CD_SNAPLEN); S.snapSync[gl] = cd(CD_SNAPSYNC);
     S.lastTerm[gl] = lastTerm; S.firstOwn[gl] = firstOwn; S.commitTerm[gl] = cTerm; S.applyHash[gl] = applyHash();
   }
 };
@@ -171,9 +170,9 @@ __device__ static inline void persist(LN &r, int L, WaveCtr *w) {
   if (n > L) n = L;
   r.cd(CD_SNAPTERM) = r.term;
   r.cd(CD_SNAPVOTE) = r.vote;
-  if (n > r.snapSync) {
-    ctr_add(w, RG_C_PERSIST_ENTRIES, (unsigned)(n - r.snapSync));
-    r.snapSync = n;
+  if (n > r.cd(CD_SNAPSYNC)) {
+    ctr_add(w, RG_C_PERSIST_ENTRIES, (unsigned)(n - r.cd(CD_SNAPSYNC)));
+    r.cd(CD_SNAPSYNC) = n;
   }
   r.cd(CD_SNAPLEN) = n;
   r.flags = (r.flags | F_SNAPHAS) & ~F_SNAPEXT;
@@ -197,14 +196,14 @@ __device__ static inline void make_peer(LN &r, const Rows &lg, const Rows &sn, i
   r.flags &= ~(F_DEAD | F_STATE_MASK | F_STOP | F_CNT_MASK | F_MONALIVE | F_FIRST | F_RESTART | F_CDIRTY);
   r.term = 0; r.vote = -1;
   *lg.termp(0, col) = 0; *lg.cmdp(0, col) = 0;
-  r.logLen = 1; r.commit = 0; r.applied = 0; r.timer = now; r.hbTimer = now;
+  r.logLen = 1; r.commit = 0; r.cd(CD_APPLIED) = 0; r.timer = now; r.hbTimer = now;
   r.lastTerm = 0; r.cTerm = 0;
   if (r.has(F_SNAPHAS) && r.cd(CD_SNAPLEN) >= 1) {
     r.term = r.cd(CD_SNAPTERM); r.vote = r.cd(CD_SNAPVOTE);
     int n = r.cd(CD_SNAPLEN);
     if (r.has(F_SNAPEXT))
-      for (int i = r.snapSync; i < n; i++) { *lg.termp(i, col) = *sn.termp(i, col); *lg.cmdp(i, col) = *sn.cmdp(i, col); }
-    if (n > r.snapSync) r.snapSync = n;
+      for (int i = r.cd(CD_SNAPSYNC); i < n; i++) { *lg.termp(i, col) = *sn.termp(i, col); *lg.cmdp(i, col) = *sn.cmdp(i, col); }
+    if (n > r.cd(CD_SNAPSYNC)) r.cd(CD_SNAPSYNC) = n;
     r.logLen = n;
     persist(r, L, w);                     // raft.go:147 runs with commitIndex still 0
     r.commit = r.logLen - 1;              // raft.go:148
@@ -228,7 +227,7 @@ __device__ static inline int start_cmd(LN &r, const Rows &lg, const Rows &sn, in
   int idx = r.logLen;
   *lg.termp(idx, col) = r.term;
   *lg.cmdp(idx, col) = cmd;
-  if (idx < r.snapSync) r.snapSync = idx;
+  if (idx < r.cd(CD_SNAPSYNC)) r.cd(CD_SNAPSYNC) = idx;
   r.logLen = idx + 1;
   r.lastTerm = r.term;
   if (idx == r.commit) r.cTerm = r.term;       // only when commitIndex already ran past the log

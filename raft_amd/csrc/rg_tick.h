@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #define rec(i) recBlk[rOff + (unsigned)(i)]
   u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
-  __shared__ int coldLds[CD_N + 5][256];    // + group words, per-lane byte-accounting sums, next client Start tick    // + two group words, + two per-lane byte-accounting sums
+  __shared__ int coldLds[CD_N + 7][256];    // + group words, per-lane byte-accounting sums, next client Start tick    // + two group words, + two per-lane byte-accounting sums
   // The last RING entries each peer wrote to its log, and the last RING records of each group, staged in LDS:
   // a follower copies a leader's fresh entries, and every peer applies its fresh entries, without a trip to
   // HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #define gPartEpoch coldLds[CD_N + 1][threadIdx.x]
   gStartSeq = Sp->startSeq[gq]; gPartEpoch = Sp->partEpoch[gq];
   if constexpr (BYTES) { coldLds[CD_N + 2][threadIdx.x] = 0; coldLds[CD_N + 3][threadIdx.x] = 0; }
-  int partNext = Sp->partNext[gq], recMax = Sp->recMax[gq];
+#define gPartNext coldLds[CD_N + 5][threadIdx.x]
+#define gRecMax coldLds[CD_N + 6][threadIdx.x]
+  gPartNext = Sp->partNext[gq]; gRecMax = Sp->recMax[gq];
   unsigned gfl = 0;
   // next ticks of the periodic control events (kept as counters: no division in the loop)
   // Within a launch each lane caches the nextIndex / matchIndex words ONE leader (cOwner) keeps for it; memory is
@@ -283,10 +285,10 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         cand = mGate < cand ? mGate : cand;
         candS = mStart < candS ? mStart : candS;
       }
-      if (r.commit > r.applied) { cand = from; candS = from; }   // entries committed by a host call are applied at once
+      if (r.commit > r.cd(CD_APPLIED)) { cand = from; candS = from; }   // entries committed by a host call are applied at once
     }
     cand = G.gmin(cand);
-    if (c.partPeriod > 0 && partNext < cand) cand = partNext;
+    if (c.partPeriod > 0 && gPartNext < cand) cand = gPartNext;
     if (c.churnPeriod > 0) {
       const int nc = ((from > 1 ? from : 1) + c.churnPeriod - 1) / c.churnPeriod * c.churnPeriod;
       if (nc < cand) cand = nc;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     }
     if (run) catch_up(t);
     // ------------------------------------------------------------ 1. control
-    const bool partNow = c.partPeriod > 0 && run && t == partNext;
+    const bool partNow = c.partPeriod > 0 && run && t == gPartNext;
     const bool churnNow = c.churnPeriod > 0 && run && t >= 1 && t % c.churnPeriod == 0;
     // a Start of a tick the group skipped precedes this tick's control events (otherwise one call below does both)
     if ((c.partPeriod > 0 || c.churnPeriod > 0) && wave_any(partNow || churnNow)) client_starts(run, t - 1);
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       unsigned ep = (unsigned)gPartEpoch;
       r.set(F_SIDE, (stream_hash(key, STREAM_PART, ep, (unsigned)peer + 1) & 1) != 0);
       u64 h = stream_hash(key, STREAM_PART, ep, 0);
-      partNext = t + c.partPeriod + (c.partJitter > 0 ? (int)(h % (u64)c.partJitter) : 0);
+      gPartNext = t + c.partPeriod + (c.partJitter > 0 ? (int)(h % (u64)c.partJitter) : 0);
       gPartEpoch++;
     }
     if (c.churnPeriod > 0 && wave_any(churnNow)) storesPending = true;
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
                   RING_PUSH(i, tm, cm);
                 }
               }
-              if (k > 0 && nx < r.snapSync) r.snapSync = nx;
+              if (k > 0 && nx < r.cd(CD_SNAPSYNC)) r.cd(CD_SNAPSYNC) = nx;
               r.logLen = lenS;
               r.lastTerm = k > 0 ? lastTermS : prevTerm;
               const int oldCommit = r.commit;
@@ -766,12 +768,12 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     // against the record, and records the rest.  Ranges of different peers that are recorded never overlap and the
     // digest is a sum, so all peers record first and then all peers check, each range in one go.
     {
-      const bool act = run && valid && !r.has(F_DEAD) && r.commit > r.applied;
+      const bool act = run && valid && !r.has(F_DEAD) && r.commit > r.cd(CD_APPLIED);
       if (wave_any(act)) {
         SECTION_COUNT(w, 4);
         const int cA = act ? r.commit : 0;
-        int pm = recMax, newMax = recMax;
-        if (wave_any(cA > recMax)) {
+        int pm = gRecMax, newMax = gRecMax;
+        if (wave_any(cA > gRecMax)) {
 #pragma unroll
           for (int u = 0; u < P; u++) {
             const int v = G.shfl(cA, u);
@@ -780,10 +782,10 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           }
         }
         const int cmpHi = cA < pm ? cA : pm;
-        const int nCmp = (act && cmpHi > r.applied) ? cmpHi - r.applied : 0;       // checks (applied, cmpHi]
-        const int recLo = r.applied > pm ? r.applied : pm;
+        const int nCmp = (act && cmpHi > r.cd(CD_APPLIED)) ? cmpHi - r.cd(CD_APPLIED) : 0;       // checks (applied, cmpHi]
+        const int recLo = r.cd(CD_APPLIED) > pm ? r.cd(CD_APPLIED) : pm;
         const int nRec = (act && r.commit > recLo) ? r.commit - recLo : 0;         // records (recLo, commit]
-        if (nRec > 0 && r.applied > pm) gfl |= RG_FLAG_APPLY_ORDER;                // config.go:184-187
+        if (nRec > 0 && r.cd(CD_APPLIED) > pm) gfl |= RG_FLAG_APPLY_ORDER;                // config.go:184-187
         if (act && r.commit >= r.logLen) gfl |= RG_FLAG_REF_PANIC;                 // raft.go:679 would index past the log
         unsigned accLo = 0, accHi = 0;
         bool bad = false;
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               }
             } while (sm);
           }
-          recMax = newMax;
+          gRecMax = newMax;
           storesPending = true;
         }
         // ---- check
@@ -836,13 +838,13 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           bool slow = nCmp > RING;
 #pragma unroll
           for (int q = 0; q < RING; q++) {
-            const int want = r.applied + 1 + ((q - r.applied - 1) & (RING - 1));
+            const int want = r.cd(CD_APPLIED) + 1 + ((q - r.cd(CD_APPLIED) - 1) & (RING - 1));
             if (want <= cmpHi && nCmp > 0 && !(ringIdx[q][tid] == want && recIdx[q][gLoc] == want)) slow = true;
           }
           u64 sm = __builtin_amdgcn_ballot_w64(slow);
           if (nCmp > 0 && !slow) {
             for (int j = 0; j < nCmp; j++) {
-              const int i = r.applied + 1 + j, q = i & (RING - 1);
+              const int i = r.cd(CD_APPLIED) + 1 + j, q = i & (RING - 1);
               const u64 cmd = ringCmd[q][tid];
               bad |= cmd != recVal[q][gLoc];
               const u64 wd = apply_word(cmd, i);
@@ -856,7 +858,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               const int src = (int)__builtin_ctzll(sm);
               sm &= sm - 1;
               const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), rOffB = (unsigned)__builtin_amdgcn_readlane((int)rOff, src);
-              const int a = __builtin_amdgcn_readlane(r.applied, src), n = __builtin_amdgcn_readlane(nCmp, src);
+              const int a = __builtin_amdgcn_readlane(r.cd(CD_APPLIED), src), n = __builtin_amdgcn_readlane(nCmp, src);
               const unsigned col = (unsigned)__builtin_amdgcn_readlane(peer, src);
               const int tTid = (tid & ~63) + src;
               bool differs = false;
@@ -875,8 +877,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         }
         if (act) {
           if (bad) gfl |= RG_FLAG_STATE_MACHINE;
-          ctr_add(w, RG_C_ENTRIES_APPLIED, (unsigned)(r.commit - r.applied));
-          r.applied = r.commit;
+          ctr_add(w, RG_C_ENTRIES_APPLIED, (unsigned)(r.commit - r.cd(CD_APPLIED)));
+          r.cd(CD_APPLIED) = r.commit;
           atomicAdd((unsigned *)&coldLds[CD_AH_LO][tid], accLo);
           atomicAdd((unsigned *)&coldLds[CD_AH_HI][tid], accHi);
         }
@@ -908,12 +910,14 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 
 #undef SYNC_STORES
 #undef RING_PUSH
-  const int startSeqOut = gStartSeq, partEpochOut = gPartEpoch;
+  const int startSeqOut = gStartSeq, partEpochOut = gPartEpoch, partNextOut = gPartNext, recMaxOut = gRecMax;
   if constexpr (BYTES) {
     if (coldLds[CD_N + 2][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 2][threadIdx.x]);
     if (coldLds[CD_N + 3][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 3][threadIdx.x]);
   }
 #undef gStartSeq
+#undef gPartNext
+#undef gRecMax
 #undef gNextStart
 #undef MS_TICK
 #undef gPartEpoch
@@ -923,7 +927,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   if (G.inWave) r.store(*Sp, gl);
   gfl = G.gor(gfl);
   if (valid && peer == 0) {
-    Sp->startSeq[g] = startSeqOut; Sp->partNext[g] = partNext; Sp->partEpoch[g] = partEpochOut; Sp->recMax[g] = recMax;
+    Sp->startSeq[g] = startSeqOut; Sp->partNext[g] = partNextOut; Sp->partEpoch[g] = partEpochOut; Sp->recMax[g] = recMaxOut;
     if (gfl) Sp->gflags[g] |= gfl;
   }
   __syncthreads();
