@@ -61,7 +61,7 @@ __global__ void k_rpc_vote(DevPtrs S, DevCfg c, int PP, const int *groups, const
     LaneT<int *> r; r.cold = coldLocal; r.cs = 1; r.load(S, gl);
     if (!r.has(F_DEAD)) {
       rg_vote_args a = args[i];
-      VoteDecision d = decide_vote(r, r.cTerm, a.term, a.candidate, a.last_log_index, a.last_log_term);
+      VoteDecision d = decide_vote(r, r.cd(CD_CTERM), a.term, a.candidate, a.last_log_index, a.last_log_term);
       commit_vote(r, d, a.term, a.candidate, now, lg, sn, p, c.L, &sctr);
       replies[i].term = d.rTerm; replies[i].granted = d.grant ? 1 : 0;
         r.store(S, gl);
@@ -102,11 +102,11 @@ __global__ void k_rpc_append(DevPtrs S, DevCfg c, int PP, const int *groups, con
           for (int j = 0; j < a.n_entries; j++) { *lg.termp(base + j, p) = eterms[a.entry_off + j]; *lg.cmdp(base + j, p) = ecmds[a.entry_off + j]; }
           if (a.n_entries > 0 && base < r.cd(CD_SNAPSYNC)) r.cd(CD_SNAPSYNC) = base;
           r.logLen = base + a.n_entries;
-          r.lastTerm = a.n_entries > 0 ? eterms[a.entry_off + a.n_entries - 1] : a.prev_log_term;
+          r.cd(CD_LASTTERM) = a.n_entries > 0 ? eterms[a.entry_off + a.n_entries - 1] : a.prev_log_term;
           if (a.leader_commit > r.commit) r.commit = (r.logLen - 1 < a.leader_commit) ? r.logLen - 1 : a.leader_commit;
           if (r.commit > r.logLen - 1) gfl |= RG_FLAG_REF_PANIC;
           __threadfence();
-          r.cTerm = *lg.termp(r.commit < c.L ? r.commit : c.L - 1, p);
+          r.cd(CD_CTERM) = *lg.termp(r.commit < c.L ? r.commit : c.L - 1, p);
           persist(r, c.L, &sctr);
           ctr_add(&sctr, RG_C_ENTRIES_REPLICATED, (unsigned)a.n_entries);
         } else {

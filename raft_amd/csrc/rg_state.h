@@ -97,7 +97,7 @@ struct WaveCtr { unsigned c[RG_CTR_SLOTS]; };
 #define STAMP_INIT do { } while (0)
 #endif
 
-enum { CD_SNAPTERM = 0, CD_SNAPVOTE, CD_SNAPLEN, CD_RNGCTR, CD_ROUNDSEQ, CD_AH_LO, CD_AH_HI, CD_APPLIED, CD_SNAPSYNC, CD_N };
+enum { CD_SNAPTERM = 0, CD_SNAPVOTE, CD_SNAPLEN, CD_RNGCTR, CD_ROUNDSEQ, CD_AH_LO, CD_AH_HI, CD_APPLIED, CD_SNAPSYNC, CD_LASTTERM, CD_FIRSTOWN, CD_CTERM, CD_N };
 
 typedef __attribute__((address_space(3))) int lds_int;
 
@@ -105,11 +105,10 @@ typedef __attribute__((address_space(3))) int lds_int;
 template <typename CP>
 struct LaneT {
   int term, vote, commit, logLen, timer, timeout, hbTimer, elNext, monNext;
-  // caches of log words (rebuilt by k_derive after host writes): term of the last entry, first index from
-  // which every entry carries the current term, term of the entry at commitIndex
-  int lastTerm, firstOwn, cTerm;
   unsigned flags;
-  // Words touched only by events (persist, draws, round numbering, apply digest) live outside the register
+  // Words touched only by events (persist, draws, round numbering, apply cursor and digest, and three caches of
+  // log words rebuilt by k_derive after host writes: term of the last entry, first index from which every entry
+  // carries the current term, term of the entry at commitIndex) live outside the register
   // file: in the tick kernel in LDS, one 256-lane row per word (cs = 256), so any lane of the group can also read
   // a peer's word directly; in the one-thread-per-command kernels in a local array (cs = 1).
   CP cold; int cs;
@@ -131,14 +130,14 @@ struct LaneT {
     logLen = S.logLen[gl]; timer = S.timer[gl]; timeout = S.timeout[gl]; hbTimer = S.hbTimer[gl]; elNext = S.elNext[gl];
     monNext = S.monNext[gl]; cd(CD_RNGCTR) = S.rngCtr[gl]; cd(CD_ROUNDSEQ) = S.roundSeq[gl];
     cd(CD_SNAPTERM) = S.snapTerm[gl]; cd(CD_SNAPVOTE) = S.snapVote[gl]; cd(CD_SNAPLEN) = S.snapLen[gl]; cd(CD_SNAPSYNC) = S.snapSync[gl];
-    lastTerm = S.lastTerm[gl]; firstOwn = S.firstOwn[gl]; cTerm = S.commitTerm[gl]; setApplyHash(S.applyHash[gl]);
+    cd(CD_LASTTERM) = S.lastTerm[gl]; cd(CD_FIRSTOWN) = S.firstOwn[gl]; cd(CD_CTERM) = S.commitTerm[gl]; setApplyHash(S.applyHash[gl]);
   }
   __device__ void store(const DevPtrs &S, long long gl) const {
     S.term[gl] = term; S.vote[gl] = vote; S.flags[gl] = (int)flags; S.commit[gl] = commit; S.applied[gl] = cd(CD_APPLIED);
     S.logLen[gl] = logLen; S.timer[gl] = timer; S.timeout[gl] = timeout; S.hbTimer[gl] = hbTimer; S.elNext[gl] = elNext;
     S.monNext[gl] = monNext; S.rngCtr[gl] = cd(CD_RNGCTR); S.roundSeq[gl] = cd(CD_ROUNDSEQ);
     S.snapTerm[gl] = cd(CD_SNAPTERM); S.snapVote[gl] = cd(CD_SNAPVOTE); S.snapLen[gl] = cd(CD_SNAPLEN); S.snapSync[gl] = cd(CD_SNAPSYNC);
-    S.lastTerm[gl] = lastTerm; S.firstOwn[gl] = firstOwn; S.commitTerm[gl] = cTerm; S.applyHash[gl] = applyHash();
+    S.lastTerm[gl] = cd(CD_LASTTERM); S.firstOwn[gl] = cd(CD_FIRSTOWN); S.commitTerm[gl] = cd(CD_CTERM); S.applyHash[gl] = applyHash();
   }
 };
 
@@ -197,7 +196,7 @@ __device__ static inline void make_peer(LN &r, const Rows &lg, const Rows &sn, i
   r.term = 0; r.vote = -1;
   *lg.termp(0, col) = 0; *lg.cmdp(0, col) = 0;
   r.logLen = 1; r.commit = 0; r.cd(CD_APPLIED) = 0; r.timer = now; r.hbTimer = now;
-  r.lastTerm = 0; r.cTerm = 0;
+  r.cd(CD_LASTTERM) = 0; r.cd(CD_CTERM) = 0;
   if (r.has(F_SNAPHAS) && r.cd(CD_SNAPLEN) >= 1) {
     r.term = r.cd(CD_SNAPTERM); r.vote = r.cd(CD_SNAPVOTE);
     int n = r.cd(CD_SNAPLEN);
@@ -208,13 +207,13 @@ __device__ static inline void make_peer(LN &r, const Rows &lg, const Rows &sn, i
     persist(r, L, w);                     // raft.go:147 runs with commitIndex still 0
     r.commit = r.logLen - 1;              // raft.go:148
     wave_fence();
-    r.lastTerm = *lg.termp(r.logLen - 1, col);
+    r.cd(CD_LASTTERM) = *lg.termp(r.logLen - 1, col);
     WAIT_LOADS();
-    r.cTerm = r.lastTerm;
+    r.cd(CD_CTERM) = r.cd(CD_LASTTERM);
   }
   r.monNext = 0;
   r.timeout = 0;
-  r.firstOwn = r.logLen;
+  r.cd(CD_FIRSTOWN) = r.logLen;
   if (!(r.term == 0 && col == 0)) r.timeout = next_random(r, key, col);
   r.elNext = now;
 }
@@ -229,8 +228,8 @@ __device__ static inline int start_cmd(LN &r, const Rows &lg, const Rows &sn, in
   *lg.cmdp(idx, col) = cmd;
   if (idx < r.cd(CD_SNAPSYNC)) r.cd(CD_SNAPSYNC) = idx;
   r.logLen = idx + 1;
-  r.lastTerm = r.term;
-  if (idx == r.commit) r.cTerm = r.term;       // only when commitIndex already ran past the log
+  r.cd(CD_LASTTERM) = r.term;
+  if (idx == r.commit) r.cd(CD_CTERM) = r.term;       // only when commitIndex already ran past the log
   persist(r, L, w);
   ctr_add(w, RG_C_ENTRIES_STARTED, 1);
   return idx;

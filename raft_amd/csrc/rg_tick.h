@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #define rec(i) recBlk[rOff + (unsigned)(i)]
   u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
-  __shared__ int coldLds[CD_N + 7][256];    // + group words, per-lane byte-accounting sums, next client Start tick    // + two group words, + two per-lane byte-accounting sums
+  __shared__ int coldLds[CD_N + 5 + (BYTES ? 2 : 0)][256];   // peer words, 5 group words, per-lane byte sums
   // The last RING entries each peer wrote to its log, and the last RING records of each group, staged in LDS:
   // a follower copies a leader's fresh entries, and every peer applies its fresh entries, without a trip to
   // HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
@@ -199,9 +199,9 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #define gStartSeq coldLds[CD_N][threadIdx.x]
 #define gPartEpoch coldLds[CD_N + 1][threadIdx.x]
   gStartSeq = Sp->startSeq[gq]; gPartEpoch = Sp->partEpoch[gq];
-  if constexpr (BYTES) { coldLds[CD_N + 2][threadIdx.x] = 0; coldLds[CD_N + 3][threadIdx.x] = 0; }
-#define gPartNext coldLds[CD_N + 5][threadIdx.x]
-#define gRecMax coldLds[CD_N + 6][threadIdx.x]
+  if constexpr (BYTES) { coldLds[CD_N + 5][threadIdx.x] = 0; coldLds[CD_N + 6][threadIdx.x] = 0; }
+#define gPartNext coldLds[CD_N + 3][threadIdx.x]
+#define gRecMax coldLds[CD_N + 4][threadIdx.x]
   gPartNext = Sp->partNext[gq]; gRecMax = Sp->recMax[gq];
   unsigned gfl = 0;
   // next ticks of the periodic control events (kept as counters: no division in the loop)
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   // (catch_up) and once more when the launch ends, so every word is as the tick-by-tick order leaves it.
   const int tEnd = t0 + nticks;
 #define MS_TICK(ms) (((ms) + (RG_TICK_MS - 1)) / RG_TICK_MS)    /* first tick whose time is >= ms (ms >= 0) */
-#define gNextStart coldLds[CD_N + 4][threadIdx.x]
+#define gNextStart coldLds[CD_N + 2][threadIdx.x]
   {
     int ns = 0x7fffffff;
     if (c.startPeriod > 0) {
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             r.vote = peer;
             persist(r, L, w);
             aLli = r.commit;
-            aLlt = r.cTerm;                                  // logs[commitIndex].Term, raft.go:583
+            aLlt = r.cd(CD_CTERM);                                  // logs[commitIndex].Term, raft.go:583
             persist(r, L, w);
             ctr_add(w, RG_C_RV_ROUNDS, 1);
           }
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           const int outW = tgt ? net_outcome(c, key, reach, s, peer, seq, delays) : 0;
           const int out = outW & 3;
           VoteDecision d; d.rTerm = 0; d.touch = d.raise = d.grant = false;
-          if (out != 0) d = decide_vote(r, r.cTerm, T, s, lli, llt);
+          if (out != 0) d = decide_vote(r, r.cd(CD_CTERM), T, s, lli, llt);
           const unsigned sdm = G.ballot(out == 2 && d.rTerm > T);      // raft.go:622
           const int b = sdm ? (__ffs((int)sdm) - 1) : NONE;
           const bool called = tgt && peer <= b, ran = out != 0 && peer <= b, ok = out == 2 && peer <= b;
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             if (wasLead && d.touch && myPos > sPos && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok), grantM = G.ballot(ok && d.grant);
-          if constexpr (BYTES) atomicAdd((unsigned *)&coldLds[CD_N + 2][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
+          if constexpr (BYTES) atomicAdd((unsigned *)&coldLds[CD_N + 5][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
           const int busy = round_busy<P>(calledM, okM, delays);
           bool won = false;
           if (wantRV) {
@@ -519,8 +519,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               r.flags |= F_MONALIVE | F_FIRST | F_CDIRTY;
               r.monNext = now + busy;
               int f = r.logLen;
-              if (r.lastTerm == r.term) { while (f > 0 && *lg.termp(f - 1, peer) == r.term) f--; }
-              r.firstOwn = f;
+              if (r.cd(CD_LASTTERM) == r.term) { while (f > 0 && *lg.termp(f - 1, peer) == r.term) f--; }
+              r.cd(CD_FIRSTOWN) = f;
               ctr_add(w, RG_C_ELECTIONS_WON, 1);
             } else {
               r.flags |= F_RESTART;
@@ -564,10 +564,10 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
                 r.flags &= ~F_CDIRTY;
                 int N = Nstar;
                 if (N > r.logLen - 1) N = r.logLen - 1;
-                if (N > r.commit && N >= r.firstOwn) {
+                if (N > r.commit && N >= r.cd(CD_FIRSTOWN)) {
                   ctr_add(w, RG_C_ENTRIES_COMMITTED, (unsigned)(N - r.commit));
                   r.commit = N;
-                  r.cTerm = r.term;                                  // N >= firstOwn
+                  r.cd(CD_CTERM) = r.term;                                  // N >= firstOwn
                   r.flags |= F_FIRST;
                   persist(r, L, w);
                 }
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           // ---------------- one replication round, raft.go:423-512
           const bool inR = G.ballot(wantAE) != 0;
           const int T = G.shfl(r.term, sIdx), lenS = G.shfl(r.logLen, sIdx), commitS = G.shfl(r.commit, sIdx);
-          const int lastTermS = G.shfl(r.lastTerm, sIdx), firstOwnS = G.shfl(r.firstOwn, sIdx), cTermS = G.shfl(r.cTerm, sIdx);
+          const int lastTermS = G.shfl(r.cd(CD_LASTTERM), sIdx), firstOwnS = G.shfl(r.cd(CD_FIRSTOWN), sIdx), cTermS = G.shfl(r.cd(CD_CTERM), sIdx);
           const unsigned seq = (unsigned)r.cold[CD_ROUNDSEQ * 256 + (sIdx - peer)];
           const unsigned fS = G.shflu(r.flags, sIdx);
           if (wantAE) r.cd(CD_ROUNDSEQ) = (int)(seq + 1u);
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           if (out != 0) {
             prevTerm = prev == lenS - 1 ? lastTermS : T;
             needS = prev != lenS - 1 && prev < firstOwnS;
-            if (prev == r.logLen - 1) myPrevTerm = r.lastTerm; else needM = prev < r.logLen - 1;
+            if (prev == r.logLen - 1) myPrevTerm = r.cd(CD_LASTTERM); else needM = prev < r.logLen - 1;
             const int pq = prev & (RING - 1);
             if (needS && ringIdx[pq][sTid] == prev) { prevTerm = ringTerm[pq][sTid]; needS = false; }
             if (needM && ringIdx[pq][tid] == prev) { myPrevTerm = ringTerm[pq][tid]; needM = false; }
@@ -687,14 +687,14 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               }
               if (k > 0 && nx < r.cd(CD_SNAPSYNC)) r.cd(CD_SNAPSYNC) = nx;
               r.logLen = lenS;
-              r.lastTerm = k > 0 ? lastTermS : prevTerm;
+              r.cd(CD_LASTTERM) = k > 0 ? lastTermS : prevTerm;
               const int oldCommit = r.commit;
               if (commitS > r.commit) r.commit = (r.logLen - 1 < commitS) ? r.logLen - 1 : commitS;
               if (r.commit > r.logLen - 1) gfl |= RG_FLAG_REF_PANIC;
               if (r.commit != oldCommit || nx <= r.commit) {          // the entry at commitIndex is new or was rewritten
-                if (r.commit == lenS - 1) r.cTerm = r.lastTerm;
-                else if (r.commit == commitS && commitS < lenS) r.cTerm = cTermS;
-                else { wave_fence(); r.cTerm = *lg.termp(r.commit < L ? r.commit : L - 1, peer); WAIT_LOADS(); }
+                if (r.commit == lenS - 1) r.cd(CD_CTERM) = r.cd(CD_LASTTERM);
+                else if (r.commit == commitS && commitS < lenS) r.cd(CD_CTERM) = cTermS;
+                else { wave_fence(); r.cd(CD_CTERM) = *lg.termp(r.commit < L ? r.commit : L - 1, peer); WAIT_LOADS(); }
               }
               persist(r, L, w);
               ctr_add(w, RG_C_ENTRIES_REPLICATED, (unsigned)k);
@@ -711,8 +711,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
           if constexpr (BYTES) {   // wire bytes: summed per target lane in LDS words of its own, added to the counters when the launch ends
-            atomicAdd((unsigned *)&coldLds[CD_N + 2][tid], called ? (unsigned)RG_APPEND_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_APPEND_REPLY_BYTES : 0u) : 0u);
-            atomicAdd((unsigned *)&coldLds[CD_N + 3][tid], (called && k > 0) ? (unsigned)k : 0u);
+            atomicAdd((unsigned *)&coldLds[CD_N + 5][tid], called ? (unsigned)RG_APPEND_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_APPEND_REPLY_BYTES : 0u) : 0u);
+            atomicAdd((unsigned *)&coldLds[CD_N + 6][tid], (called && k > 0) ? (unsigned)k : 0u);
           }
           const int busy = round_busy<P>(calledM, okM, delays);
           int rTermB = 0;
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               if (cn > 3) r.flags |= F_STOP;
             }
             r.hbTimer = now + busy;                                  // raft.go:521
-            { int N = nAfter; if (N > r.logLen - 1) N = r.logLen - 1; if (ruleOpen || (N > r.commit && N >= r.firstOwn)) r.flags |= F_CDIRTY; }
+            { int N = nAfter; if (N > r.logLen - 1) N = r.logLen - 1; if (ruleOpen || (N > r.commit && N >= r.cd(CD_FIRSTOWN))) r.flags |= F_CDIRTY; }
             if (busy > 0) { r.monNext = now + busy; monAct = false; }   // the loop goes on once the waits are over
           }
           storesPending = true;
@@ -912,8 +912,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #undef RING_PUSH
   const int startSeqOut = gStartSeq, partEpochOut = gPartEpoch, partNextOut = gPartNext, recMaxOut = gRecMax;
   if constexpr (BYTES) {
-    if (coldLds[CD_N + 2][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 2][threadIdx.x]);
-    if (coldLds[CD_N + 3][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 3][threadIdx.x]);
+    if (coldLds[CD_N + 5][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 5][threadIdx.x]);
+    if (coldLds[CD_N + 6][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 6][threadIdx.x]);
   }
 #undef gStartSeq
 #undef gPartNext
