@@ -294,11 +294,10 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       if (nc < cand) cand = nc;
     }
     if (c.startPeriod > 0 && wave_any(startOn && sTick < cand)) {
-      // The Start comes before anything else.  It changes no clock but its taker's gate, so it is not an event of its
-      // own: the group next runs when the taker's (earlier) poll passes the gate, at the Start after it at the latest.
+      // The Start comes before anything else.  It changes no clock but its taker's gate (which then stays the
+      // backlog one however many Starts follow), so it is not an event of its own: the group next runs when the
+      // taker's (earlier) poll passes the gate.
       candS = G.gmin(candS);
-      const int lim = sTick + c.startPeriod;
-      candS = candS < lim ? candS : lim;
       if (startOn && sTick < cand) cand = candS < cand ? candS : cand;
     }
     return cand > from ? cand : from;
