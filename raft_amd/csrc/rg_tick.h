@@ -309,15 +309,17 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     for (;;) {
       const bool startNow = c.startPeriod > 0 && on && gNextStart <= upTo && gStartSeq < c.startMax;
       if (!(c.startPeriod > 0 && wave_any(startNow))) break;
-      if (startNow) gNextStart += c.startPeriod;
       // client Starts: config.go:436-451 (first connected leader) / test_test.go:697-703 (every leader)
       bool cand = startNow && valid && r.isLeader() && (c.startMode == RG_START_ALL || r.has(F_CONNECTED));
+      const unsigned mAll = G.ballot(cand);
+      if (startNow && mAll == 0) { do gNextStart += c.startPeriod; while (gNextStart <= upTo); }   // nobody to ask: these Starts change nothing
       if (wave_any(cand)) {
         SECTION_COUNT(w, 5);
         bool room = cand && r.logLen < L;
-        unsigned mAll = G.ballot(cand), mRoom = G.ballot(room);
+        const unsigned mRoom = G.ballot(room);
         unsigned below = (1u << peer) - 1u;
         if (c.startMode == RG_START_ALL) {
+          if (startNow && mAll) gNextStart += c.startPeriod;
           int seq = gStartSeq + __popc(mRoom & below);
           bool tried = cand && seq < c.startMax;
           if (tried) {
@@ -327,17 +329,26 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           }
           int acc = __popc(mRoom);
           int left = c.startMax - gStartSeq;
-          gStartSeq += acc < left ? acc : (left > 0 ? left : 0);
-        } else if (gStartSeq < c.startMax) {
-          // peers without room are tried (and flagged) until one accepts
-          int wIdx = mRoom ? (__ffs((int)mRoom) - 1) : NONE;
-          if (cand && peer <= wIdx) {
-            u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)gStartSeq);
-            const int at = start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
-            if (at >= 0) RING_PUSH(at, r.term, cmd);
+          if (mAll) gStartSeq += acc < left ? acc : (left > 0 ? left : 0);
+        } else {
+          // Peers without room are tried (and flagged) until one accepts.  Nothing else happens to the group between
+          // the Starts that are due, so the peer that accepts takes them all, as far as its log has room.
+          const int wIdx = mRoom ? (__ffs((int)mRoom) - 1) : NONE;
+          int due = 0;
+          if (startNow && mAll) { do { gNextStart += c.startPeriod; due++; } while (gNextStart <= upTo && gStartSeq + due < c.startMax); }
+          int take = (cand && peer == wIdx) ? (due < L - r.logLen ? due : L - r.logLen) : 0;
+          take = G.shfl(take, wIdx < NONE ? wIdx : 0);
+          if (wIdx == NONE) take = 0;
+          if (startNow && mAll && wIdx < NONE && take < due) gNextStart -= (due - take) * c.startPeriod;   // the rest goes round again
+          if (cand && peer < wIdx) (void)start_cmd(r, lg, sn, peer, L, 0, gfl, w);            // full log: refused and flagged
+          if (cand && peer == wIdx) {
+            for (int j = 0; j < take; j++) {
+              u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)(gStartSeq + j));
+              const int at = start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
+              if (at >= 0) RING_PUSH(at, r.term, cmd);
+            }
           }
-          if (mRoom) gStartSeq++;
-          (void)mAll;
+          if (startNow && mAll) gStartSeq += take;
         }
         storesPending = true;
       }
