@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #define nextRow(i) nextBlk[mOff + (unsigned)(i)]
 #define matchRow(i) matchBlk[mOff + (unsigned)(i)]
   u64 *const recBlk = H.applyRec + (size_t)g0 * L;
-  const unsigned rOff = gLoc * (unsigned)L;
+  unsigned gLocL = gLoc;                 // laundered once per pass: offsets derived from it are recomputed, not kept
+  int peerL = peer;
+#define rOff (gLocL * (unsigned)L)
 #define rec(i) recBlk[rOff + (unsigned)(i)]
   u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         int tau = MS_TICK(r.elNext);
         while (tau < T) {
           const int ms = tau * RG_TICK_MS;
-          r.elNext = ms + RG_ELECTION_PERIOD_MS + extra + sleep_slack(key, peer, ms);
+          r.elNext = ms + RG_ELECTION_PERIOD_MS + extra + sleep_slack(key, peerL, ms);
           tau = MS_TICK(r.elNext);
         }
       }
@@ -369,6 +371,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
       asm volatile("" : "+v"(klo), "+v"(khi));
       key = ((u64)khi << 32) | klo;
+      asm volatile("" : "+v"(peerL), "+v"(gLocL));
     }
     if (run) catch_up(t);
     // ------------------------------------------------------------ 1. control
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         int st = r.state();
         if (st == RG_FOLLOWER) {
           if (now - r.timer > r.timeout) { pend = true; pendLocal = true; }
-          else r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);   // nothing later in this tick can make it fire
+          else r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peerL, now);   // nothing later in this tick can make it fire
         } else if (st == RG_CANDIDATE) pend = true;
         else specEl = true;
       }
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           r.setState(RG_CANDIDATE);
           r.timeout = next_random(r, key, peer);
           ctr_add(w, RG_C_TIMEOUTS, 1);
-          r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);
+          r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peerL, now);
           pend = false;
         }
       }
@@ -463,11 +466,11 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               r.timeout = next_random(r, key, peer);
               ctr_add(w, RG_C_TIMEOUTS, 1);
             }
-            r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);
+            r.elNext = now + RG_ELECTION_PERIOD_MS + sleep_slack(key, peerL, now);
           } else if (st == RG_CANDIDATE) {
             wantRV = true;
           } else {
-            r.elNext = now + RG_ELECTION_PERIOD_MS + RG_ELECTION_LEADER_EXTRA_MS + sleep_slack(key, peer, now);
+            r.elNext = now + RG_ELECTION_PERIOD_MS + RG_ELECTION_LEADER_EXTRA_MS + sleep_slack(key, peerL, now);
           }
         }
         STAMP(5);
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             } else {
               r.flags |= F_RESTART;
             }
-            r.elNext = now + busy + RG_ELECTION_PERIOD_MS + sleep_slack(key, peer, now);
+            r.elNext = now + busy + RG_ELECTION_PERIOD_MS + sleep_slack(key, peerL, now);
           }
           const bool grpWon = G.ballot(won) != 0;
           int lenW = 0;
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
         }
         if (isS) pend = false;
       }
-      if (specEl) r.elNext = now + RG_ELECTION_PERIOD_MS + RG_ELECTION_LEADER_EXTRA_MS + sleep_slack(key, peer, now);
+      if (specEl) r.elNext = now + RG_ELECTION_PERIOD_MS + RG_ELECTION_LEADER_EXTRA_MS + sleep_slack(key, peerL, now);
       if (specMon) r.monNext = now + RG_MONITOR_POLL_MS;
     }
 
@@ -934,6 +937,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #undef nextRow
 #undef matchRow
 #undef rec
+#undef rOff
   if (G.inWave) r.store(*Sp, gl);
   gfl = G.gor(gfl);
   if (valid && peer == 0) {
