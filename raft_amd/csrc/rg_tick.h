@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #define rec(i) recBlk[rOff + (unsigned)(i)]
   u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
-  __shared__ int coldLds[CD_N + 5 + (BYTES ? 2 : 0)][256];   // peer words, 5 group words, per-lane byte sums
+  __shared__ int coldLds[CD_N + 6 + (BYTES ? 2 : 0)][256];   // peer words, 5 group words, the checked-apply cursor, per-lane byte sums
   // The last RING entries each peer wrote to its log, and the last RING records of each group, staged in LDS:
   // a follower copies a leader's fresh entries, and every peer applies its fresh entries, without a trip to
   // HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
 #define gStartSeq coldLds[CD_N][threadIdx.x]
 #define gPartEpoch coldLds[CD_N + 1][threadIdx.x]
   gStartSeq = Sp->startSeq[gq]; gPartEpoch = Sp->partEpoch[gq];
-  if constexpr (BYTES) { coldLds[CD_N + 5][threadIdx.x] = 0; coldLds[CD_N + 6][threadIdx.x] = 0; }
+#define lVerified coldLds[CD_N + 5][threadIdx.x]
+  lVerified = r.cd(CD_APPLIED);
+  if constexpr (BYTES) { coldLds[CD_N + 6][threadIdx.x] = 0; coldLds[CD_N + 7][threadIdx.x] = 0; }
 #define gPartNext coldLds[CD_N + 3][threadIdx.x]
 #define gRecMax coldLds[CD_N + 4][threadIdx.x]
   gPartNext = Sp->partNext[gq]; gRecMax = Sp->recMax[gq];
@@ -305,6 +307,45 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     return cand > from ? cand : from;
   };
 
+  // The tester's side of apply (config.go:170-194: compare the delivered command with the record of its index,
+  // fold it into the peer's digest) looks at nothing but the entry and the record, and neither changes once
+  // written unless the peer's log is rewritten below its apply cursor.  So it is not done entry by entry as the
+  // cursor moves: lVerified trails r.applied, and the stretch between them is checked by the whole wave (one entry
+  // per lane) before anything could overwrite one of its entries, and when the launch ends.
+  auto verify_applied = [&](bool want) {
+    const bool need = want && valid && lVerified < r.cd(CD_APPLIED);
+    u64 vm = __builtin_amdgcn_ballot_w64(need);
+    if (vm) {
+      SECTION_COUNT(w, 12);
+      SYNC_STORES();
+      const int nOwn = r.cd(CD_APPLIED) - lVerified;
+      do {
+        const int src = (int)__builtin_ctzll(vm);
+        vm &= vm - 1;
+        const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), rOffB = (unsigned)__builtin_amdgcn_readlane((int)rOff, src);
+        const int a = __builtin_amdgcn_readlane(lVerified, src), n = __builtin_amdgcn_readlane(nOwn, src);
+        const unsigned col = (unsigned)__builtin_amdgcn_readlane(peer, src);
+        const int tTid = (tid & ~63) + src;
+        bool differs = false;
+        unsigned accLo = 0, accHi = 0;
+        for (int j = G.lane; j < n; j += 64) {
+          const int i = a + 1 + j, ic = i < L ? i : L - 1;
+          const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
+          const u64 seen = recBlk[rOffB + (unsigned)ic];
+          differs |= cmd != seen;
+          const u64 wd = apply_word(cmd, i);
+          accLo += (unsigned)wd; accHi += (unsigned)(wd >> 32);
+        }
+        if (G.lane < n) {
+          atomicAdd((unsigned *)&coldLds[CD_AH_LO][tTid], accLo);
+          atomicAdd((unsigned *)&coldLds[CD_AH_HI][tTid], accHi);
+        }
+        if (wave_any(differs) && G.lane == src) gfl |= RG_FLAG_STATE_MACHINE;
+      } while (vm);
+      if (need) lVerified = r.cd(CD_APPLIED);
+    }
+  };
+
   // Client Starts of the lane's group that are due up to tick `upTo` (next_event lets a group skip the tick of a
   // Start and accounts for what the Start changes; Start() itself does not look at the clock).
   auto client_starts = [&](bool on, int upTo) {
@@ -317,6 +358,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       if (startNow && mAll == 0) { do gNextStart += c.startPeriod; while (gNextStart <= upTo); }   // nobody to ask: these Starts change nothing
       if (wave_any(cand)) {
         SECTION_COUNT(w, 5);
+        if (wave_any(cand && r.logLen <= r.cd(CD_APPLIED))) verify_applied(cand && r.logLen <= r.cd(CD_APPLIED));
         bool room = cand && r.logLen < L;
         const unsigned mRoom = G.ballot(room);
         unsigned below = (1u << peer) - 1u;
@@ -386,7 +428,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       gPartNext = t + c.partPeriod + (c.partJitter > 0 ? (int)(h % (u64)c.partJitter) : 0);
       gPartEpoch++;
     }
-    if (c.churnPeriod > 0 && wave_any(churnNow)) storesPending = true;
+    if (c.churnPeriod > 0 && wave_any(churnNow)) { storesPending = true; verify_applied(churnNow && r.has(F_DEAD)); }   // a restart replays the log
     if (churnNow) {                                                  // test_test.go:893-919
       unsigned it = (unsigned)(t / c.churnPeriod);
       u64 h1 = stream_hash(key, STREAM_CHURN, it, 0), h2 = stream_hash(key, STREAM_CHURN, it, 1), h3 = stream_hash(key, STREAM_CHURN, it, 2);
@@ -394,6 +436,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
       if ((int)((unsigned)(h2 & 0xFFFFF) % 1000u) < c.churnRestart && valid && peer == (int)((h2 >> 32) % (u64)P)) {
         if (r.has(F_DEAD)) {
           make_peer(r, lg, sn, peer, L, key, now, w);
+          lVerified = 0;                                       // lastApplied starts again from 0
 #pragma unroll
           for (int q = 0; q < RING; q++) ringIdx[q][tid] = -1;     // the log may have been rebuilt from an imported blob
         }
@@ -510,7 +553,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             if (wasLead && d.touch && myPos > sPos && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok), grantM = G.ballot(ok && d.grant);
-          if constexpr (BYTES) atomicAdd((unsigned *)&coldLds[CD_N + 5][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
+          if constexpr (BYTES) atomicAdd((unsigned *)&coldLds[CD_N + 6][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
           const int busy = round_busy<P>(calledM, okM, delays);
           bool won = false;
           if (wantRV) {
@@ -660,6 +703,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               if (want < lenS && ringIdx[q][sTid] != want) viaHbm = true;
             }
           }
+          // entries at or below the receiver's apply cursor are about to be rewritten: check them first
+          if (wave_any(ran && d.touch && d.match && nx <= r.cd(CD_APPLIED))) verify_applied(ran && d.touch && d.match && nx <= r.cd(CD_APPLIED));
           {
             u64 hm = __builtin_amdgcn_ballot_w64(viaHbm);
             const bool scan = ok && b != peer && d.touch && !d.match;
@@ -724,8 +769,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
           if constexpr (BYTES) {   // wire bytes: summed per target lane in LDS words of its own, added to the counters when the launch ends
-            atomicAdd((unsigned *)&coldLds[CD_N + 5][tid], called ? (unsigned)RG_APPEND_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_APPEND_REPLY_BYTES : 0u) : 0u);
-            atomicAdd((unsigned *)&coldLds[CD_N + 6][tid], (called && k > 0) ? (unsigned)k : 0u);
+            atomicAdd((unsigned *)&coldLds[CD_N + 6][tid], called ? (unsigned)RG_APPEND_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_APPEND_REPLY_BYTES : 0u) : 0u);
+            atomicAdd((unsigned *)&coldLds[CD_N + 7][tid], (called && k > 0) ? (unsigned)k : 0u);
           }
           const int busy = round_busy<P>(calledM, okM, delays);
           int rTermB = 0;
@@ -778,13 +823,14 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     // ------------------------------------------------------------ 3. apply, raft.go:676-686 + config.go:170-194
     // The reference's tester sees peers 0..P-1 deliver in turn: peer p checks its entries up to the newest index
     // recorded before its turn (pm = the larger of the record's end and the commitIndex of every lower peer)
-    // against the record, and records the rest.  Ranges of different peers that are recorded never overlap and the
-    // digest is a sum, so all peers record first and then all peers check, each range in one go.
+    // against the record, and records the rest.  Ranges of different peers that are recorded never overlap.  Here
+    // the cursor moves and new indices are recorded at once; the checks and the digest follow in verify_applied.
     {
       const bool act = run && valid && !r.has(F_DEAD) && r.commit > r.cd(CD_APPLIED);
       if (wave_any(act)) {
         SECTION_COUNT(w, 4);
         const int cA = act ? r.commit : 0;
+        const int applied = r.cd(CD_APPLIED);
         int pm = gRecMax, newMax = gRecMax;
         if (wave_any(cA > gRecMax)) {
 #pragma unroll
@@ -794,15 +840,10 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
             newMax = v > newMax ? v : newMax;
           }
         }
-        const int cmpHi = cA < pm ? cA : pm;
-        const int nCmp = (act && cmpHi > r.cd(CD_APPLIED)) ? cmpHi - r.cd(CD_APPLIED) : 0;       // checks (applied, cmpHi]
-        const int recLo = r.cd(CD_APPLIED) > pm ? r.cd(CD_APPLIED) : pm;
+        const int recLo = applied > pm ? applied : pm;
         const int nRec = (act && r.commit > recLo) ? r.commit - recLo : 0;         // records (recLo, commit]
-        if (nRec > 0 && r.cd(CD_APPLIED) > pm) gfl |= RG_FLAG_APPLY_ORDER;                // config.go:184-187
+        if (nRec > 0 && applied > pm) gfl |= RG_FLAG_APPLY_ORDER;                  // config.go:184-187
         if (act && r.commit >= r.logLen) gfl |= RG_FLAG_REF_PANIC;                 // raft.go:679 would index past the log
-        unsigned accLo = 0, accHi = 0;
-        bool bad = false;
-        // ---- record
         if (wave_any(nRec > 0)) {
           bool slow = nRec > RING;
 #pragma unroll
@@ -817,8 +858,6 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               const u64 cmd = ringCmd[q][tid];
               rec(i < L ? i : L - 1) = cmd;
               if (i > newMax - RING) { recIdx[q][gLoc] = i; recVal[q][gLoc] = cmd; }
-              const u64 wd = apply_word(cmd, i);
-              accLo += (unsigned)wd; accHi += (unsigned)(wd >> 32);
             }
           }
           if (sm) {                                   // long or old runs: the whole wave, one entry per lane
@@ -831,69 +870,20 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               const int lo = __builtin_amdgcn_readlane(recLo, src), n = __builtin_amdgcn_readlane(nRec, src);
               const int top = __builtin_amdgcn_readlane(newMax, src), gSrc = __builtin_amdgcn_readlane((int)gLoc, src);
               const unsigned col = (unsigned)__builtin_amdgcn_readlane(peer, src);
-              const int tTid = (tid & ~63) + src;
               for (int j = G.lane; j < n; j += 64) {
                 const int i = lo + 1 + j, ic = i < L ? i : L - 1, q = i & (RING - 1);
                 const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
                 recBlk[rOffB + (unsigned)ic] = cmd;
                 if (i > top - RING) { recIdx[q][gSrc] = i; recVal[q][gSrc] = cmd; }
-                const u64 wd = apply_word(cmd, i);
-                atomicAdd((unsigned *)&coldLds[CD_AH_LO][tTid], (unsigned)wd);
-                atomicAdd((unsigned *)&coldLds[CD_AH_HI][tTid], (unsigned)(wd >> 32));
               }
             } while (sm);
           }
           gRecMax = newMax;
           storesPending = true;
         }
-        // ---- check
-        if (wave_any(nCmp > 0)) {
-          bool slow = nCmp > RING;
-#pragma unroll
-          for (int q = 0; q < RING; q++) {
-            const int want = r.cd(CD_APPLIED) + 1 + ((q - r.cd(CD_APPLIED) - 1) & (RING - 1));
-            if (want <= cmpHi && nCmp > 0 && !(ringIdx[q][tid] == want && recIdx[q][gLoc] == want)) slow = true;
-          }
-          u64 sm = __builtin_amdgcn_ballot_w64(slow);
-          if (nCmp > 0 && !slow) {
-            for (int j = 0; j < nCmp; j++) {
-              const int i = r.cd(CD_APPLIED) + 1 + j, q = i & (RING - 1);
-              const u64 cmd = ringCmd[q][tid];
-              bad |= cmd != recVal[q][gLoc];
-              const u64 wd = apply_word(cmd, i);
-              accLo += (unsigned)wd; accHi += (unsigned)(wd >> 32);
-            }
-          }
-          if (sm) {
-            SECTION_COUNT(w, 12);
-            SYNC_STORES();
-            do {
-              const int src = (int)__builtin_ctzll(sm);
-              sm &= sm - 1;
-              const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), rOffB = (unsigned)__builtin_amdgcn_readlane((int)rOff, src);
-              const int a = __builtin_amdgcn_readlane(r.cd(CD_APPLIED), src), n = __builtin_amdgcn_readlane(nCmp, src);
-              const unsigned col = (unsigned)__builtin_amdgcn_readlane(peer, src);
-              const int tTid = (tid & ~63) + src;
-              bool differs = false;
-              for (int j = G.lane; j < n; j += 64) {
-                const int i = a + 1 + j, ic = i < L ? i : L - 1;
-                const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
-                const u64 seen = recBlk[rOffB + (unsigned)ic];
-                differs |= cmd != seen;
-                const u64 wd = apply_word(cmd, i);
-                atomicAdd((unsigned *)&coldLds[CD_AH_LO][tTid], (unsigned)wd);
-                atomicAdd((unsigned *)&coldLds[CD_AH_HI][tTid], (unsigned)(wd >> 32));
-              }
-              if (wave_any(differs) && G.lane == src) bad = true;
-            } while (sm);
-          }
-        }
         if (act) {
-          if (bad) gfl |= RG_FLAG_STATE_MACHINE;
-          ctr_add(w, RG_C_ENTRIES_APPLIED, (unsigned)(r.commit - r.cd(CD_APPLIED)));
+          ctr_add(w, RG_C_ENTRIES_APPLIED, (unsigned)(r.commit - applied));
           r.cd(CD_APPLIED) = r.commit;
-          atomicAdd((unsigned *)&coldLds[CD_AH_LO][tid], accLo);
-          atomicAdd((unsigned *)&coldLds[CD_AH_HI][tid], accHi);
         }
       }
     }
@@ -920,15 +910,17 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   }
   client_starts(valid, tEnd - 1);          // Starts and wake-ups the groups skipped towards the end of the launch
   catch_up(tEnd);
+  verify_applied(valid);
 
 #undef SYNC_STORES
 #undef RING_PUSH
   const int startSeqOut = gStartSeq, partEpochOut = gPartEpoch, partNextOut = gPartNext, recMaxOut = gRecMax;
   if constexpr (BYTES) {
-    if (coldLds[CD_N + 5][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 5][threadIdx.x]);
-    if (coldLds[CD_N + 6][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 6][threadIdx.x]);
+    if (coldLds[CD_N + 6][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 6][threadIdx.x]);
+    if (coldLds[CD_N + 7][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 7][threadIdx.x]);
   }
 #undef gStartSeq
+#undef lVerified
 #undef gPartNext
 #undef gRecMax
 #undef gNextStart
