@@ -261,7 +261,10 @@ __device__ static inline void commit_vote(LN &r, const VoteDecision &d, int aTer
 struct AppendDecision { int rTerm, ct, ci; bool touch, match; };
 // AppendEntries(), raft.go:270-321, evaluated without side effects.
 // myPrevTerm is logs[PrevLogIndex].Term of the receiver (any value if out of range).
-template <class LN>
+// SCAN = false leaves the walk back to the first index of the conflicting term (raft.go:308-313) to the caller:
+// ci is then RG_CI_PENDING.
+#define RG_CI_PENDING (-0x7fffffff)
+template <bool SCAN = true, class LN>
 __device__ static inline AppendDecision decide_append(const LN &r, const Rows &lg, int col, int aTerm, int prev, int prevTerm, int myPrevTerm) {
   AppendDecision d; d.ct = 0; d.ci = 0; d.match = false;
   if (aTerm < r.term) { d.rTerm = r.term; d.touch = false; return d; }
@@ -270,6 +273,7 @@ __device__ static inline AppendDecision decide_append(const LN &r, const Rows &l
   if (prev + 1 <= r.logLen && myPrevTerm == prevTerm) { d.match = true; return d; }
   if (prev + 1 > r.logLen) { d.ct = -1; d.ci = r.logLen; return d; }
   d.ct = myPrevTerm;
+  if constexpr (!SCAN) { d.ci = RG_CI_PENDING; return d; }
   int idx = prev - 1;
   while (idx >= 0 && *lg.termp(idx, col) == d.ct) idx--;
   d.ci = idx + 1;

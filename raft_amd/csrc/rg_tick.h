@@ -688,7 +688,28 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
               WAIT_LOADS();
             }
           }
-          if (out != 0) d = decide_append(r, lg, peer, T, prev, prevTerm, myPrevTerm);
+          if (out != 0) d = decide_append<false>(r, lg, peer, T, prev, prevTerm, myPrevTerm);
+          {   // raft.go:308-313, the walk back to the first index of the conflicting term: by the wave, 64 entries a step
+            u64 cm = __builtin_amdgcn_ballot_w64(out == 2 && d.ci == RG_CI_PENDING);   // only a reply that arrives carries it
+            if (cm) {
+              SYNC_STORES();
+              do {
+                const int src = (int)__builtin_ctzll(cm);
+                cm &= cm - 1;
+                const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), col = (unsigned)__builtin_amdgcn_readlane(peer, src);
+                const int ct = __builtin_amdgcn_readlane(d.ct, src);
+                int base = __builtin_amdgcn_readlane(prev, src) - 1, ci;
+                for (;;) {
+                  const int ix = base - G.lane;
+                  const bool stop = ix < 0 || *(int *)(lg.base + (size_t)(offB + (unsigned)ix * (unsigned)lg.rowBytes + col * 4u)) != ct;
+                  const u64 sm = __builtin_amdgcn_ballot_w64(stop);
+                  if (sm) { ci = base - (int)__builtin_ctzll(sm) + 1; break; }
+                  base -= 64;
+                }
+                if (G.lane == src) d.ci = ci;
+              } while (cm);
+            }
+          }
           const unsigned sdm = G.ballot(out == 2 && d.rTerm > T);    // raft.go:482
           const int b = sdm ? (__ffs((int)sdm) - 1) : NONE;
           const bool called = tgt2 && peer <= b, ran = out != 0 && peer <= b, ok = out == 2 && peer <= b;
@@ -764,8 +785,27 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           // the leader's handling of each reply, done by the replying lane
           if (ok && b != peer) {
             if (d.match) { cNext = lenS; cMatch = lenS - 1; matchRow(sIdx * PP + peer) = cMatch; }
-            else cNext = leader_backoff(lg, sIdx, nx, d.ct, d.ci);   // a stale-term reply would have ended the round
+            else cNext = d.ci;                                       // raft.go:493-505; the walk over the leader's log follows
             nextRow(sIdx * PP + peer) = cNext;
+          }
+          {   // raft.go:495-502: the leader looks for its last entry of the conflicting term, by the wave
+            const bool walk = ok && b != peer && !d.match && d.ct >= 0;
+            u64 wm = __builtin_amdgcn_ballot_w64(walk);
+            while (wm) {
+              const int src = (int)__builtin_ctzll(wm);
+              wm &= wm - 1;
+              const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), col = (unsigned)__builtin_amdgcn_readlane(sIdx, src);
+              const int ct = __builtin_amdgcn_readlane(d.ct, src);
+              int base = __builtin_amdgcn_readlane(nx, src) - 1, hit, hitTerm;
+              for (;;) {                                 // ends at index 0 at the latest: its term 0 is not above ct
+                const int ix = base - G.lane;
+                const int tmv = ix >= 0 ? *(int *)(lg.base + (size_t)(offB + (unsigned)ix * (unsigned)lg.rowBytes + col * 4u)) : 0;
+                const u64 sm = __builtin_amdgcn_ballot_w64(tmv <= ct);
+                if (sm) { const int f = (int)__builtin_ctzll(sm); hit = base - f; hitTerm = __builtin_amdgcn_readlane(tmv, f); break; }
+                base -= 64;
+              }
+              if (G.lane == src && hitTerm == ct) { cNext = hit + 1; nextRow(sIdx * PP + peer) = cNext; }
+            }
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
           if constexpr (BYTES) {   // wire bytes: summed per target lane in LDS words of its own, added to the counters when the launch ends
@@ -885,6 +925,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
           ctr_add(w, RG_C_ENTRIES_APPLIED, (unsigned)(r.commit - applied));
           r.cd(CD_APPLIED) = r.commit;
         }
+        // keep the unchecked stretch short, so that a check forced by a rewrite (in the middle of a round) is one step
+        if (wave_any(act && r.commit - lVerified >= 48)) verify_applied(act && r.commit - lVerified >= 48);
       }
     }
 
