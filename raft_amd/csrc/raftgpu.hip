@@ -136,50 +136,18 @@ static void fill_devcfg(rg_engine *e) {
   e->tickBlocks = d.nbA + (rest + 4 * d.gwB - 1) / (4 * d.gwB);
 }
 
-// Make for every peer: device memsets plus a host-built image of the few non-zero words.
+// Make for every peer: one kernel for the per-peer and per-group words, memsets for the rows.
 static int init_state(rg_engine *e) {
   const long long nL = e->nLanes;
   DevPtrs &S = e->S;
   hipStream_t st = e->stream;
-  int *zeroed[] = {S.term, S.commit, S.applied, S.timer, S.hbTimer, S.elNext, S.monNext, S.roundSeq, S.snapTerm, S.snapVote, S.snapLen, S.lastTerm, S.commitTerm};
-  for (int *p : zeroed) HIPCHK(hipMemsetAsync(p, 0, nL * 4, st));
-  HIPCHK(hipMemsetAsync(S.applyHash, 0, nL * 8, st));
-  HIPCHK(hipMemsetAsync(S.vote, 0xFF, nL * 4, st));            // -1
-  HIPCHK(hipMemsetAsync(S.nextIdx, 0, (size_t)e->Gpad * e->PP * e->PP * 4, st));
-  HIPCHK(hipMemsetAsync(S.matchIdx, 0, (size_t)e->Gpad * e->PP * e->PP * 4, st));
+  hipLaunchKernelGGL(k_init, dim3((unsigned)((nL + 255) / 256)), dim3(256), 0, st, S, e->dc, e->PP, nL);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipMemsetAsync(S.logRows, 0, (size_t)e->G * e->L * e->rowBytes, st));
   if (S.snapRows) HIPCHK(hipMemsetAsync(S.snapRows, 0, (size_t)e->G * e->L * e->rowBytes, st));
   HIPCHK(hipMemsetAsync(S.applyRec, 0, (size_t)e->G * e->L * 8, st));
-  HIPCHK(hipMemsetAsync(S.startSeq, 0, (size_t)e->Gpad * 4, st));
-  HIPCHK(hipMemsetAsync(S.partEpoch, 0, (size_t)e->Gpad * 4, st));
-  HIPCHK(hipMemsetAsync(S.recMax, 0, (size_t)e->Gpad * 4, st));
-  HIPCHK(hipMemsetAsync(S.gflags, 0, (size_t)e->Gpad * 4, st));
   HIPCHK(hipMemsetAsync(S.counters, 0, RG_CTR_SLOTS * 8, st));
   HIPCHK(hipMemsetAsync(S.flagSummary, 0, 8, st));
-  // words that depend on (group, peer): flags, logLen, snapSync, firstOwn, timeout, rngCtr, partNext
-  std::vector<int> flags(nL, 0), one(nL, 0), timeout(nL, 0), rng(nL, 0), pn(e->Gpad, 0);
-  const u64 seedKey = sm64(e->cfg.seed);
-  for (int g = 0; g < e->G; g++) {
-    const u64 key = sm64(seedKey ^ (u64)(e->cfg.group_base + g));
-    pn[g] = e->cfg.part_period > 0 ? e->cfg.part_period : 0;
-    for (int p = 0; p < e->P; p++) {
-      long long gl = (long long)g * e->PP + p;
-      flags[gl] = (int)F_CONNECTED;
-      one[gl] = 1;
-      if (p != 0) {                                              // raft.go:545-547
-        u64 h = stream_hash(key, STREAM_ELECTION, (unsigned)p, 0);
-        timeout[gl] = (int)((unsigned)(h >> 32) % (unsigned)RG_TIMEOUT_SPAN_MS) + RG_TIMEOUT_BASE_MS;
-        rng[gl] = 1;
-      }
-    }
-  }
-  HIPCHK(hipMemcpyAsync(S.flags, flags.data(), nL * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(S.logLen, one.data(), nL * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(S.snapSync, one.data(), nL * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(S.firstOwn, one.data(), nL * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(S.timeout, timeout.data(), nL * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(S.rngCtr, rng.data(), nL * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(S.partNext, pn.data(), (size_t)e->Gpad * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   e->now = 0; e->derivedDirty = false; e->syncDirty = false;
   std::fill(e->drained.begin(), e->drained.end(), 0);

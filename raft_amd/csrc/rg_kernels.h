@@ -123,6 +123,32 @@ __global__ void k_rpc_append(DevPtrs S, DevCfg c, int PP, const int *groups, con
   if (threadIdx.x < RG_N_COUNTERS && sctr.c[threadIdx.x]) atomicAdd((unsigned long long *)&S.counters[threadIdx.x], (unsigned long long)sctr.c[threadIdx.x]);
 }
 
+// Make for every peer (raft.go:526-568): every per-peer and per-group word of a fresh engine, one thread per lane.
+// Lanes past the last group or peer hold zeros.
+__global__ void k_init(DevPtrs S, DevCfg c, int PP, long long nLanes) {
+  long long gl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gl >= nLanes) return;
+  const int g = (int)(gl / PP), p = (int)(gl % PP);
+  const bool peer = g < c.G && p < c.P;
+  int timeout = 0;
+  if (peer && p != 0) {                                          // raft.go:545-547
+    const u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
+    const u64 h = stream_hash(key, STREAM_ELECTION, (unsigned)p, 0);
+    timeout = (int)((unsigned)(h >> 32) % (unsigned)RG_TIMEOUT_SPAN_MS) + RG_TIMEOUT_BASE_MS;
+  }
+  S.term[gl] = 0; S.vote[gl] = -1; S.commit[gl] = 0; S.applied[gl] = 0; S.timer[gl] = 0; S.hbTimer[gl] = 0;
+  S.elNext[gl] = 0; S.monNext[gl] = 0; S.roundSeq[gl] = 0; S.snapTerm[gl] = 0; S.snapVote[gl] = 0; S.snapLen[gl] = 0;
+  S.lastTerm[gl] = 0; S.commitTerm[gl] = 0; S.applyHash[gl] = 0;
+  S.flags[gl] = peer ? (int)F_CONNECTED : 0;
+  S.logLen[gl] = peer; S.snapSync[gl] = peer; S.firstOwn[gl] = peer;
+  S.timeout[gl] = timeout; S.rngCtr[gl] = peer && p != 0;
+  for (int q = 0; q < PP; q++) { S.nextIdx[gl * PP + q] = 0; S.matchIdx[gl * PP + q] = 0; }
+  if (p == 0) {
+    S.startSeq[g] = 0; S.partEpoch[g] = 0; S.recMax[g] = 0; S.gflags[g] = 0;
+    S.partNext[g] = g < c.G && c.partPeriod > 0 ? c.partPeriod : 0;
+  }
+}
+
 // (re)build the derived words after the host wrote state directly
 __global__ void k_derive(DevPtrs S, DevCfg c, int PP, int resetSync) {
   long long gl = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -2,9 +2,10 @@
 
 Groups never exchange messages (reference: src/raft/config.go:70 builds a
 private network per group), so the data path needs no collective.  The only
-exchange is this one: 17 counters (sum), the flag bits (max, i.e. OR) and the
-number of flagged groups (sum) -- a few hundred bytes, latency bound.  With
-backend "nccl" this is RCCL over xGMI; tests run it over gloo on CPU.
+exchange is this one all-reduce (sum) of a few hundred bytes, latency bound: the
+counters, one word per flag bit (the number of ranks that saw it; non-zero = set,
+which is the OR) and the number of flagged groups.  With backend "nccl" this is
+RCCL over xGMI; tests run it over gloo on CPU.
 """
 import torch
 import torch.distributed as dist
@@ -27,15 +28,14 @@ def pack(counters, flags, flagged_groups, device):
 def unpack(t):
     v = t.tolist()
     counters = dict(zip(COUNTERS, v[:N_COUNTERS]))
-    flags = sum(int(b) << i for i, b in enumerate(v[N_COUNTERS:N_COUNTERS + N_FLAG_BITS]))
+    flags = sum((1 << i) for i, b in enumerate(v[N_COUNTERS:N_COUNTERS + N_FLAG_BITS]) if b)
     return counters, flags, int(v[N_COUNTERS + N_FLAG_BITS])
 
 
 def all_reduce_summary(counters, flags, flagged_groups, device):
     """Returns (counters, flags, flagged_groups) over all ranks; identity when not distributed."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return dict(counters), flags, flagged_groups
     t = pack(counters, flags, flagged_groups, device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t[:N_COUNTERS], op=dist.ReduceOp.SUM)
-        dist.all_reduce(t[N_COUNTERS:N_COUNTERS + N_FLAG_BITS], op=dist.ReduceOp.MAX)
-        dist.all_reduce(t[N_COUNTERS + N_FLAG_BITS:], op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return unpack(t)
