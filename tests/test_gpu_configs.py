@@ -1,8 +1,11 @@
 """The named benchmark configurations, HIP engine vs CPU oracle (-m gpu).
 
-Reduced group counts run the whole schedule on both sides and compare per-group digests of every
-Raft-visible word, counters and flags.  The full-size runs compare a sample of shards: all seeded
-streams key on the global group id, so the oracle can replay any slice of the groups by itself."""
+Reduced group counts run the whole schedule on both sides, in two launches, and compare per-group digests
+of every Raft-visible word, counters and flags after each.  The full-size runs compare every group after
+one launch: all seeded streams key on the global group id, so the oracle replays the groups slice by slice
+(on the host cores, a few seconds per configuration)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -60,22 +63,32 @@ def test_whole_schedule_reduced(name, kw, groups, ticks):
         assert c["ae_conflicts"] > 0 and c["persist_entries"] > 0
 
 
-def _sampled_shards(kw, groups, ticks, shards, width, engine_base=0):
+THREADS = min(16, os.cpu_count() or 1)
+
+
+def _every_group(kw, groups, ticks, width, engine_base=0):
+    """One engine launch over all groups; the oracle replays them `width` groups at a time."""
     e = _engine(n_groups=groups, group_base=engine_base, **kw)
     e.step(ticks)
     h = e.state_hash()
     fl = e.read("gflags")
-    for first in shards:
-        o = _oracle(n_groups=width, group_base=engine_base + first, **kw)
-        o.step_mt(ticks, 8)
-        assert np.array_equal(o.state_hash(), h[first:first + width]), "shard at group %d" % first
-        assert np.array_equal(o.read("gflags"), fl[first:first + width])
+    total = dict.fromkeys(e.counters(), 0)
+    for first in range(0, groups, width):
+        n = min(width, groups - first)
+        o = _oracle(n_groups=n, group_base=engine_base + first, **kw)
+        o.step_mt(ticks, THREADS)
+        assert np.array_equal(o.state_hash(), h[first:first + n]), "groups %d..%d" % (first, first + n)
+        assert np.array_equal(o.read("gflags"), fl[first:first + n]), "flags of groups %d..%d" % (first, first + n)
+        for k, v in o.counters().items():
+            total[k] += v
+        o.close()
+    assert total == e.counters()
     return e
 
 
-def test_cfg3_full_size_sampled_shards():
+def test_cfg3_full_size_every_group():
     """65,536 five-peer groups, 10 % + 10 % loss, rolling partitions, 20,000 ticks in one launch."""
-    e = _sampled_shards(CFG3, 65536, 20000, (0, 21845, 40000, 65536 - 96), 96)
+    e = _every_group(CFG3, 65536, 20000, 8192)
     c = e.counters()
     assert c["group_ticks"] == 65536 * 20000
     # properties that need no oracle, on the groups in which the reference's code stays inside its own invariants
@@ -93,10 +106,10 @@ def test_cfg3_full_size_sampled_shards():
 def test_cfg5_shard_of_a_million_groups():
     """One rank's 131,072 three-peer groups of the 1,048,576-group job (rank 5 of 8): the result of a
     shard depends only on its global group ids."""
-    _sampled_shards(CFG5, 131072, 4000, (0, 70000, 131072 - 128), 128, engine_base=5 * 131072)
+    _every_group(CFG5, 131072, 4000, 16384, engine_base=5 * 131072)
 
 
-def test_cfg4_full_size_sampled_shards():
+def test_cfg4_full_size_every_group():
     """16,384 seven-peer groups, 4096-entry logs, crash / restart churn."""
-    e = _sampled_shards(CFG4, 16384, 40000, (0, 9000, 16384 - 32), 32)
+    e = _every_group(CFG4, 16384, 40000, 2048)
     assert e.counters()["ae_conflicts"] > 0
