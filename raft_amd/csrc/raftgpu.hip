@@ -43,7 +43,9 @@ struct rg_engine {
   rg_config cfg;
   int G, P, L, PP, Gpad, gpb, rowBytes, cmdOff;
   int slotWaves;        // wavefronts of the tick kernel the device holds at once
-  int tickBlocks;       // grid of the tick kernel (DevCfg::nbA blocks of gwA groups per wave, then blocks of gwB)
+  int tickBlocks;       // grid of a plain launch of the tick kernel (DevCfg::nbA blocks of gwA groups per wave, then blocks of gwB)
+  int relaySets;        // sets of a relay launch (full waves only); 0 when the groups fit the chip at once
+  int *relay;           // device: [0] next item, [1 + set] chunks done
   long long nLanes;
   DevPtrs S;
   DevPtrs *dS;          // device copy of S: the tick kernel reads the cold pointers through it
@@ -134,6 +136,9 @@ static void fill_devcfg(rg_engine *e) {
   if (const char *ov = getenv("RAFTGPU_TAIL_GROUPS_PER_WAVE")) gwB = atoi(ov);   // tuning aid
   d.gwB = gwB < 1 ? 1 : (gwB > gwMax ? gwMax : gwB);
   e->tickBlocks = d.nbA + (rest + 4 * d.gwB - 1) / (4 * d.gwB);
+  d.relaySets = 0; d.relayChunk = 0;
+  // more groups than the chip holds at once: long launches go through the relay queue (see k_tick)
+  e->relaySets = e->G > cap ? (int)((e->G + 4 * gwMax - 1) / (4 * gwMax)) : 0;
 }
 
 // Make for every peer: one kernel for the per-peer and per-group words, memsets for the rows.
@@ -193,6 +198,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   e->gpb = 4 * (64 / e->P);          // groups per block of the tick kernel: 64/P whole groups per wave
   e->Gpad = (e->G + e->gpb - 1) / e->gpb * e->gpb + e->gpb;   // thinner waves reach up to one block past the last group
   e->slotWaves = prop.multiProcessorCount * 4 * RG_TICK_WAVES;
+  if (const char *ov = getenv("RAFTGPU_SLOT_WAVES")) { int v = atoi(ov); if (v >= 4) e->slotWaves = v / 4 * 4; }   // test aid: pretend the chip is smaller
   e->nLanes = (long long)e->Gpad * e->PP;
   e->cmdOff = (e->P * 4 + 7) & ~7;
   e->rowBytes = (e->cmdOff + e->P * 8 + 15) & ~15;
@@ -217,9 +223,11 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (rc == RG_OK) rc = dalloc(e, &S.gflags, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.counters, (size_t)RG_CTR_SLOTS);
   if (rc == RG_OK) rc = dalloc(e, &S.flagSummary, (size_t)2);
+  if (rc == RG_OK) rc = dalloc(e, &e->relay, (size_t)(e->Gpad / e->gpb + 2));
   if (rc != RG_OK) { free_engine(e); return rc; }
   e->drained.assign((size_t)e->G * e->P, 0);
   fill_devcfg(e);
+  e->H.relay = e->relay;
   e->H.logRows = S.logRows; e->H.snapRows = S.snapRows; e->H.nextIdx = S.nextIdx; e->H.matchIdx = S.matchIdx; e->H.applyRec = S.applyRec;
   if (dalloc(e, &e->dS, 1) != RG_OK || hipMemcpy(e->dS, &e->S, sizeof(DevPtrs), hipMemcpyHostToDevice) != hipSuccess) { free_engine(e); return RG_ERR_NOMEM; }
   rc = init_state(e);
@@ -278,15 +286,39 @@ static int run_derive(rg_engine *e) {
 // thousand per tick, so one launch covers at most this many ticks.
 #define RG_MAX_LAUNCH_TICKS 500000
 
+// Ticks per chunk of a relay launch: chunks of at least RG_RELAY_MIN_TICKS, at most RG_RELAY_MAX_CHUNKS of them
+// (a chunk boundary costs a store and a load of the state and a cold start of the LDS rings; measured on 65,536
+// five-peer groups x 20,000 ticks: 67.2 ms plain, 58.1 / 56.4 / 55.4 / 56.4 / 59.7 ms with 2 / 4 / 6 / 12 / 24
+// chunks; a light workload, 131,072 three-peer groups x 4,000 ticks at 1 % loss, loses with 2 chunks: 9.3 ms
+// against 8.5 ms plain).  0: plain launch.
+#define RG_RELAY_MIN_TICKS 3000
+#define RG_RELAY_MAX_CHUNKS 6
+static int relay_chunk_ticks(const rg_engine *e, int n_ticks) {
+  if (e->relaySets == 0) return 0;
+  int k = n_ticks / RG_RELAY_MIN_TICKS;
+  if (k > RG_RELAY_MAX_CHUNKS) k = RG_RELAY_MAX_CHUNKS;
+  if (const char *ov = getenv("RAFTGPU_RELAY_CHUNKS")) k = atoi(ov);   // tuning aid; 0 or 1: plain launches
+  if (k < 2) return 0;
+  return (n_ticks + k - 1) / k;
+}
+
 static int launch_ticks(rg_engine *e, int n_ticks) {
   hipEvent_t a, b;
   HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-  const int blocks = e->tickBlocks;
+  DevCfg dc = e->dc;
+  int blocks = e->tickBlocks;
+  const int chunk = relay_chunk_ticks(e, n_ticks);
+  if (chunk > 0) {
+    dc.relaySets = e->relaySets; dc.relayChunk = chunk;
+    dc.nbA = e->relaySets; dc.gwA = 64 / e->P;                 // every set holds full waves
+    blocks = e->relaySets * ((n_ticks + chunk - 1) / chunk);   // one block per item
+    HIPCHK(hipMemsetAsync(e->relay, 0, (size_t)(e->relaySets + 1) * sizeof(int), e->stream));
+  }
   HIPCHK(hipEventRecord(a, e->stream));
   const DevPtrs *dS = e->dS;
 #define TICK_LAUNCH(PEERS) do { \
-    if (e->dc.acctBytes) hipLaunchKernelGGL((k_tick<PEERS, true>), dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, n_ticks); \
-    else hipLaunchKernelGGL((k_tick<PEERS, false>), dim3(blocks), dim3(256), 0, e->stream, dS, e->H, e->dc, (int)e->now, n_ticks); } while (0)
+    if (dc.acctBytes) hipLaunchKernelGGL((k_tick<PEERS, true>), dim3(blocks), dim3(256), 0, e->stream, dS, e->H, dc, (int)e->now, n_ticks); \
+    else hipLaunchKernelGGL((k_tick<PEERS, false>), dim3(blocks), dim3(256), 0, e->stream, dS, e->H, dc, (int)e->now, n_ticks); } while (0)
   switch (e->P) {
   case 2: TICK_LAUNCH(2); break;
   case 3: TICK_LAUNCH(3); break;

@@ -29,7 +29,8 @@ struct DevCfg {
   int partPeriod, partJitter;
   int churnPeriod, churnDisc, churnRestart, churnCrash;
   int acctBytes;
-  int nbA, gwA, gwB;             // tick kernel: blocks [0, nbA) hold gwA groups per wave, the others gwB
+  int nbA, gwA, gwB;             // tick kernel: sets [0, nbA) hold gwA groups per wave, the others gwB
+  int relaySets, relayChunk;     // relay launch: number of sets (0: plain launch) and ticks per chunk
 };
 
 // packed per-peer flag word
@@ -153,7 +154,10 @@ __device__ static inline Rows rows_of(char *arr, const DevCfg &c, int g) {
   Rows r; r.base = arr + (size_t)g * c.L * c.rowBytes; r.off = 0; r.rowBytes = c.rowBytes; r.cmdOff = c.cmdOff; return r;
 }
 // the arrays the tick loop itself touches; everything else is read once and written once
-struct HotPtrs { char *logRows, *snapRows; int *nextIdx, *matchIdx; u64 *applyRec; };
+struct HotPtrs {
+  char *logRows, *snapRows; int *nextIdx, *matchIdx; u64 *applyRec;
+  int *relay;                    // relay launches: [0] next item, [1 + set] chunks of the set that are done
+};
 
 __device__ static inline void ctr_add(WaveCtr *w, int which, unsigned v) { atomicAdd(&w->c[which], v); }
 

@@ -141,23 +141,21 @@ __device__ static inline int turn_start(u64 key, int tick, int P) {
 #ifndef RG_TICK_WAVES
 #define RG_TICK_WAVES 4   // waves per SIMD the register allocation must allow
 #endif
-// BYTES: wire-byte accounting compiled in (rg_config.account_bytes); the plain instantiation carries none of it
+// Ticks [t0, t0 + nticks) of one block's worth of groups (`set`: what blockIdx.x is in a plain launch), by the
+// whole block.  BYTES: wire-byte accounting compiled in (rg_config.account_bytes); the plain instantiation
+// carries none of it.  w: the calling wave's counters of the launch.
 template <int P, bool BYTES>
-__global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
+__device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, const DevCfg &c, const int set, const int t0, const int nticks, WaveCtr *w) {
   constexpr int PP = P <= 4 ? 4 : 8;        // stride of a group in the per-peer arrays and matrices in memory
   constexpr int NONE = 8;                   // "no such peer" for first-set-bit results
   constexpr int GPB = 4 * GrpN<P>::GWMAX;   // most groups of a 256-thread block
-  __shared__ WaveCtr sctr[4];
-  // blocks [0, nbA) hold gwA groups per wave, the rest gwB
-  const bool classA = (int)blockIdx.x < c.nbA;
+  // sets [0, nbA) hold gwA groups per wave, the rest gwB
+  const bool classA = set < c.nbA;
   const int gw = classA ? c.gwA : c.gwB;
   const GrpN<P> G(gw);
   const int wave = (int)(threadIdx.x >> 6);
-  WaveCtr *w = &sctr[wave];
-  if (G.lane < RG_CTR_SLOTS) w->c[G.lane] = 0;
-  __syncthreads();
 
-  const int g0 = classA ? (int)blockIdx.x * 4 * c.gwA : c.nbA * 4 * c.gwA + ((int)blockIdx.x - c.nbA) * 4 * c.gwB;   // the block's first group: always < G
+  const int g0 = classA ? set * 4 * c.gwA : c.nbA * 4 * c.gwA + (set - c.nbA) * 4 * c.gwB;   // the set's first group: always < G
   const int g = g0 + wave * gw + (G.lane / P);
   const int peer = G.peer;
   const bool valid = G.inWave && g < c.G;
@@ -978,8 +976,55 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     Sp->startSeq[g] = startSeqOut; Sp->partNext[g] = partNextOut; Sp->partEpoch[g] = partEpochOut; Sp->recMax[g] = recMaxOut;
     if (gfl) Sp->gflags[g] |= gfl;
   }
+}
+
+// The tick kernel.  Plain launch (c.relaySets == 0): block b runs set b through all nticks.
+//
+// Relay launch: every wave costs about the same time whatever its groups do, so a launch of 1 1/3 times the
+// groups the chip holds would take as long as one of 2 times.  Instead the work is cut into items (set, chunk of
+// c.relayChunk ticks), one block each, and a block takes its item from a counter when it starts, in chunk-major
+// order: as blocks finish, the dispatcher starts the next ones, so all SIMDs stay busy until the last items.  Item
+// (set, k) needs the state item (set, k - 1) stored, possibly by a block on another XCD: the finisher publishes
+// relay[1 + set] = k with agent-scope release after a fence, the taker spins on it with acquire.  A block only ever
+// waits for an item drawn before its own, i.e. by a block that is already running, so the smallest unfinished item
+// never waits and every block ends.  A chunk boundary is what a launch boundary is: the result does not depend on
+// the cut.
+template <int P, bool BYTES>
+__global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
+  __shared__ WaveCtr sctr[4];
+  __shared__ int sItem;
+  const int lane = (int)(threadIdx.x & 63);
+  WaveCtr *w = &sctr[threadIdx.x >> 6];
+  if (lane < RG_CTR_SLOTS) w->c[lane] = 0;
+  int set = (int)blockIdx.x;
+  if (c.relaySets > 0) {
+    if (threadIdx.x == 0) sItem = atomicAdd(H.relay, 1);
+    __syncthreads();
+    const int chunk = sItem / c.relaySets;
+    set = sItem - chunk * c.relaySets;
+    const int from = chunk * c.relayChunk;          // < nticks: the grid is exactly the items
+    t0 += from;
+    nticks = nticks - from < c.relayChunk ? nticks - from : c.relayChunk;
+    if (chunk > 0) {
+      if (threadIdx.x == 0) {
+        while (__hip_atomic_load(&H.relay[1 + set], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) __builtin_amdgcn_s_sleep(64);
+      }
+      __syncthreads();
+      __threadfence();
+    }
+  }
   __syncthreads();
-  if (G.lane < RG_CTR_SLOTS && w->c[G.lane]) atomicAdd((unsigned long long *)&Sp->counters[G.lane], (unsigned long long)w->c[G.lane]);
+  tick_span<P, BYTES>(Sp, H, c, set, t0, nticks, w);
+  if (c.relaySets > 0) {
+    __threadfence();
+    __syncthreads();                                 // every wave's stores are out
+    if (threadIdx.x == 0) {
+      const int chunk = sItem / c.relaySets;
+      __hip_atomic_store(&H.relay[1 + sItem - chunk * c.relaySets], chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (lane < RG_CTR_SLOTS && w->c[lane]) atomicAdd((unsigned long long *)&Sp->counters[lane], (unsigned long long)w->c[lane]);
 }
 
 #endif

@@ -1,0 +1,40 @@
+"""Relay launches of the tick kernel (-m gpu): more sets of groups than resident blocks, the launch cut into
+chunks that blocks take from a queue, each chunk continuing from the state another block stored.  The engine is
+told the chip is tiny (RAFTGPU_SLOT_WAVES) so that small cases take that path; whatever the cut, every word has to
+match the tick-by-tick oracle."""
+import pytest
+
+from raft_amd import _abi
+from tests.parity import diff_states
+
+pytestmark = pytest.mark.gpu
+
+LOSSY = dict(n_peers=5, log_cap=300, seed=11, req_drop_permille=100, reply_drop_permille=100, start_period=3, start_max=280,
+             part_period=60, part_jitter=20)
+CHURN = dict(n_peers=7, log_cap=300, seed=12, req_drop_permille=50, reply_drop_permille=50, start_period=4, start_max=290,
+             start_mode=_abi.START_ALL, churn_period=35, churn_disconnect_permille=200, churn_restart_permille=500,
+             churn_crash_permille=200, account_bytes=1)
+THREE = dict(n_peers=3, log_cap=96, seed=13, req_drop_permille=10, reply_drop_permille=10, start_period=5, start_max=90)
+
+
+@pytest.mark.parametrize("kw,groups,slot_waves,chunks,launches", [
+    (LOSSY, 200, 8, 3, (700, 1, 299, 500)),         # 5 sets on 2 blocks
+    (LOSSY, 500, 16, 7, (1500,)),                   # 11 sets on 4 blocks, 7 chunks
+    (CHURN, 150, 4, 4, (400, 400, 401)),            # 5 sets on 1 block: the block relays to itself
+    (THREE, 1000, 12, 5, (250, 1000)),              # 12 sets on 3 blocks
+    (LOSSY, 96, 8, 4, (600,)),                      # 2 sets on 2 blocks: no relay needed, plain launch
+])
+def test_relay_matches_oracle(monkeypatch, kw, groups, slot_waves, chunks, launches):
+    from oracle.binding import OracleEngine
+    from raft_amd import Engine
+    monkeypatch.setenv("RAFTGPU_SLOT_WAVES", str(slot_waves))
+    monkeypatch.setenv("RAFTGPU_RELAY_CHUNKS", str(chunks))
+    cfg = dict(kw, n_groups=groups)
+    o, e = OracleEngine(_abi.make_config(**cfg)), Engine(_abi.make_config(**cfg))
+    for n in launches:
+        o.step_mt(n, 8)
+        e.step(n)
+        d = diff_states(o, e)
+        assert not d, "; ".join(d[:5])
+    assert e.counters() == o.counters()
+    assert e.counters()["entries_committed"] > 0
