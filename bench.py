@@ -184,7 +184,8 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "kernel": "k_tick", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-            "mode": ("fused: peer scalars stay in registers across the %d ticks of a launch" % launch) if launch > 1
+            "mode": ("fused: peer scalars stay in registers and LDS within a launch of %d ticks (cut into relay chunks of "
+                     "at least 3,000 ticks when the groups exceed what the chip holds at once)" % launch) if launch > 1
                     else "streamed: every peer's state is loaded and stored once per tick",
         },
         "safety_flags": flags, "flagged_groups": flagged_groups,

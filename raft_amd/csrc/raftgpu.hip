@@ -44,8 +44,9 @@ struct rg_engine {
   int G, P, L, PP, Gpad, gpb, rowBytes, cmdOff;
   int slotWaves;        // wavefronts of the tick kernel the device holds at once
   int tickBlocks;       // grid of a plain launch of the tick kernel (DevCfg::nbA blocks of gwA groups per wave, then blocks of gwB)
-  int relaySets;        // sets of a relay launch (full waves only); 0 when the groups fit the chip at once
+  int relaySets, relayGw;   // sets of a relay launch and groups per wave in them; 0 when the groups fit the chip at once
   int *relay;           // device: [0] next item, [1 + set] chunks done
+  int *relayStage;      // device: per-group words in transit between the blocks of a relay launch
   long long nLanes;
   DevPtrs S;
   DevPtrs *dS;          // device copy of S: the tick kernel reads the cold pointers through it
@@ -137,8 +138,18 @@ static void fill_devcfg(rg_engine *e) {
   d.gwB = gwB < 1 ? 1 : (gwB > gwMax ? gwMax : gwB);
   e->tickBlocks = d.nbA + (rest + 4 * d.gwB - 1) / (4 * d.gwB);
   d.relaySets = 0; d.relayChunk = 0;
-  // more groups than the chip holds at once: long launches go through the relay queue (see k_tick)
-  e->relaySets = e->G > cap ? (int)((e->G + 4 * gwMax - 1) / (4 * gwMax)) : 0;
+  // More groups than the chip holds at once: long launches go through the relay queue (see k_tick).  There a set's
+  // state passes from block to block within a launch, so no 128-byte line of any array may hold words of two
+  // sets: the waves of a relay launch hold the most groups for which every array's bytes per set are whole lines.
+  e->relaySets = 0; e->relayGw = 0;
+  if (e->G > cap) {
+    for (int gw = gwMax; gw >= gwMax - 1 && gw >= 1; gw--) {
+      const long long gs = 4 * gw;                               // groups per set
+      const bool whole = gs * e->PP * 4 % 128 == 0 && gs * e->PP * e->PP * 4 % 128 == 0 &&
+                         gs * e->L * e->rowBytes % 128 == 0 && gs * e->L * 8 % 128 == 0;
+      if (whole) { e->relayGw = gw; e->relaySets = (int)((e->G + gs - 1) / gs); break; }
+    }
+  }
 }
 
 // Make for every peer: one kernel for the per-peer and per-group words, memsets for the rows.
@@ -223,11 +234,15 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (rc == RG_OK) rc = dalloc(e, &S.gflags, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.counters, (size_t)RG_CTR_SLOTS);
   if (rc == RG_OK) rc = dalloc(e, &S.flagSummary, (size_t)2);
-  if (rc == RG_OK) rc = dalloc(e, &e->relay, (size_t)(e->Gpad / e->gpb + 2));
   if (rc != RG_OK) { free_engine(e); return rc; }
   e->drained.assign((size_t)e->G * e->P, 0);
   fill_devcfg(e);
-  e->H.relay = e->relay;
+  if (e->relaySets > 0) {
+    rc = dalloc(e, &e->relay, (size_t)e->relaySets + 1);
+    if (rc == RG_OK) rc = dalloc(e, &e->relayStage, (size_t)e->relaySets * 5 * ((e->gpb + 31) / 32 * 32));
+    if (rc != RG_OK) { free_engine(e); return rc; }
+  }
+  e->H.relay = e->relay; e->H.relayStage = e->relayStage;
   e->H.logRows = S.logRows; e->H.snapRows = S.snapRows; e->H.nextIdx = S.nextIdx; e->H.matchIdx = S.matchIdx; e->H.applyRec = S.applyRec;
   if (dalloc(e, &e->dS, 1) != RG_OK || hipMemcpy(e->dS, &e->S, sizeof(DevPtrs), hipMemcpyHostToDevice) != hipSuccess) { free_engine(e); return RG_ERR_NOMEM; }
   rc = init_state(e);
@@ -310,10 +325,11 @@ static int launch_ticks(rg_engine *e, int n_ticks) {
   const int chunk = relay_chunk_ticks(e, n_ticks);
   if (chunk > 0) {
     dc.relaySets = e->relaySets; dc.relayChunk = chunk;
-    dc.nbA = e->relaySets; dc.gwA = 64 / e->P;                 // every set holds full waves
+    dc.nbA = e->relaySets; dc.gwA = e->relayGw;
     blocks = e->relaySets * ((n_ticks + chunk - 1) / chunk);   // one block per item
     HIPCHK(hipMemsetAsync(e->relay, 0, (size_t)(e->relaySets + 1) * sizeof(int), e->stream));
   }
+  if (getenv("RAFTGPU_TRACE_LAUNCH")) fprintf(stderr, "raftgpu: k_tick ticks=%d blocks=%d relay_sets=%d relay_chunk=%d groups_per_wave=%d\n", n_ticks, blocks, dc.relaySets, dc.relayChunk, dc.gwA);
   HIPCHK(hipEventRecord(a, e->stream));
   const DevPtrs *dS = e->dS;
 #define TICK_LAUNCH(PEERS) do { \

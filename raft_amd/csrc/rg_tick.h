@@ -143,9 +143,11 @@ __device__ static inline int turn_start(u64 key, int tick, int P) {
 #endif
 // Ticks [t0, t0 + nticks) of one block's worth of groups (`set`: what blockIdx.x is in a plain launch), by the
 // whole block.  BYTES: wire-byte accounting compiled in (rg_config.account_bytes); the plain instantiation
-// carries none of it.  w: the calling wave's counters of the launch.
+// carries none of it.  w: the calling wave's counters of the launch.  stIn / stOut: the set's group words as the
+// previous span left them / for the next span, when spans of one launch run on different blocks (else null).
 template <int P, bool BYTES>
-__device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, const DevCfg &c, const int set, const int t0, const int nticks, WaveCtr *w) {
+__device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, const DevCfg &c, const int set, const int t0, const int nticks, WaveCtr *w,
+                                          const int *stIn, int *stOut) {
   constexpr int PP = P <= 4 ? 4 : 8;        // stride of a group in the per-peer arrays and matrices in memory
   constexpr int NONE = 8;                   // "no such peer" for first-set-bit results
   constexpr int GPB = 4 * GrpN<P>::GWMAX;   // most groups of a 256-thread block
@@ -198,13 +200,14 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   r.load(*Sp, gl);                       // tail lanes read a valid slot and never write it back
 #define gStartSeq coldLds[CD_N][threadIdx.x]
 #define gPartEpoch coldLds[CD_N + 1][threadIdx.x]
-  gStartSeq = Sp->startSeq[gq]; gPartEpoch = Sp->partEpoch[gq];
+  constexpr int GPBPAD = (GPB + 31) & ~31;
+  gStartSeq = stIn ? stIn[gLoc] : Sp->startSeq[gq]; gPartEpoch = stIn ? stIn[GPBPAD + gLoc] : Sp->partEpoch[gq];
 #define lVerified coldLds[CD_N + 5][threadIdx.x]
   lVerified = r.cd(CD_APPLIED);
   if constexpr (BYTES) { coldLds[CD_N + 6][threadIdx.x] = 0; coldLds[CD_N + 7][threadIdx.x] = 0; }
 #define gPartNext coldLds[CD_N + 3][threadIdx.x]
 #define gRecMax coldLds[CD_N + 4][threadIdx.x]
-  gPartNext = Sp->partNext[gq]; gRecMax = Sp->recMax[gq];
+  gPartNext = stIn ? stIn[2 * GPBPAD + gLoc] : Sp->partNext[gq]; gRecMax = stIn ? stIn[3 * GPBPAD + gLoc] : Sp->recMax[gq];
   unsigned gfl = 0;
   // next ticks of the periodic control events (kept as counters: no division in the loop)
   // Within a launch each lane caches the nextIndex / matchIndex words ONE leader (cOwner) keeps for it; memory is
@@ -974,7 +977,12 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   gfl = G.gor(gfl);
   if (valid && peer == 0) {
     Sp->startSeq[g] = startSeqOut; Sp->partNext[g] = partNextOut; Sp->partEpoch[g] = partEpochOut; Sp->recMax[g] = recMaxOut;
-    if (gfl) Sp->gflags[g] |= gfl;
+    if (stOut) {
+      const unsigned all = (stIn ? (unsigned)stIn[4 * GPBPAD + gLoc] : Sp->gflags[g]) | gfl;
+      stOut[gLoc] = startSeqOut; stOut[GPBPAD + gLoc] = partEpochOut; stOut[2 * GPBPAD + gLoc] = partNextOut; stOut[3 * GPBPAD + gLoc] = recMaxOut;
+      stOut[4 * GPBPAD + gLoc] = (int)all;
+      if (gfl) Sp->gflags[g] = all;
+    } else if (gfl) Sp->gflags[g] |= gfl;
   }
 }
 
@@ -988,7 +996,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 // relay[1 + set] = k with agent-scope release after a fence, the taker spins on it with acquire.  A block only ever
 // waits for an item drawn before its own, i.e. by a block that is already running, so the smallest unfinished item
 // never waits and every block ends.  A chunk boundary is what a launch boundary is: the result does not depend on
-// the cut.
+// the cut.  Adjacent sets share 128-byte lines of the per-group arrays, and a line this XCD's L2 holds with bytes
+// of its own to write back is not known to be refetched for its other bytes: the per-group words travel through
+// a staging area with whole lines per set instead (the host lays out relay launches so that no other array has
+// a line with two sets in it).
 template <int P, bool BYTES>
 __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
   __shared__ WaveCtr sctr[4];
@@ -997,6 +1008,8 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   WaveCtr *w = &sctr[threadIdx.x >> 6];
   if (lane < RG_CTR_SLOTS) w->c[lane] = 0;
   int set = (int)blockIdx.x;
+  const int *stIn = nullptr;
+  int *stOut = nullptr;
   if (c.relaySets > 0) {
     if (threadIdx.x == 0) sItem = atomicAdd(H.relay, 1);
     __syncthreads();
@@ -1005,19 +1018,20 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     const int from = chunk * c.relayChunk;          // < nticks: the grid is exactly the items
     t0 += from;
     nticks = nticks - from < c.relayChunk ? nticks - from : c.relayChunk;
+    constexpr int STAGE = 5 * ((4 * GrpN<P>::GWMAX + 31) & ~31);       // ints per set
+    stOut = H.relayStage + (size_t)set * STAGE;
+    if (chunk > 0) stIn = stOut;
     if (chunk > 0) {
       if (threadIdx.x == 0) {
         while (__hip_atomic_load(&H.relay[1 + set], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) __builtin_amdgcn_s_sleep(64);
       }
-      __syncthreads();
-      __threadfence();
+      __syncthreads();                               // the acquire invalidated this CU's vector cache for all its waves
     }
   }
   __syncthreads();
-  tick_span<P, BYTES>(Sp, H, c, set, t0, nticks, w);
+  tick_span<P, BYTES>(Sp, H, c, set, t0, nticks, w, stIn, stOut);
   if (c.relaySets > 0) {
-    __threadfence();
-    __syncthreads();                                 // every wave's stores are out
+    __syncthreads();                                 // every wave's stores have reached the L2; thread 0's release writes it back
     if (threadIdx.x == 0) {
       const int chunk = sItem / c.relaySets;
       __hip_atomic_store(&H.relay[1 + sItem - chunk * c.relaySets], chunk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

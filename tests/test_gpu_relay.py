@@ -17,18 +17,19 @@ CHURN = dict(n_peers=7, log_cap=300, seed=12, req_drop_permille=50, reply_drop_p
 THREE = dict(n_peers=3, log_cap=96, seed=13, req_drop_permille=10, reply_drop_permille=10, start_period=5, start_max=90)
 
 
-@pytest.mark.parametrize("kw,groups,slot_waves,chunks,launches", [
-    (LOSSY, 200, 8, 3, (700, 1, 299, 500)),         # 5 sets on 2 blocks
-    (LOSSY, 500, 16, 7, (1500,)),                   # 11 sets on 4 blocks, 7 chunks
-    (CHURN, 150, 4, 4, (400, 400, 401)),            # 5 sets on 1 block: the block relays to itself
-    (THREE, 1000, 12, 5, (250, 1000)),              # 12 sets on 3 blocks
-    (LOSSY, 96, 8, 4, (600,)),                      # 2 sets on 2 blocks: no relay needed, plain launch
+@pytest.mark.parametrize("kw,groups,slot_waves,chunks,launches,sets", [
+    (LOSSY, 200, 8, 3, (700, 1, 299, 500), 5),      # 5 sets of 48 groups, room for 2 blocks
+    (LOSSY, 500, 16, 7, (1500,), 11),               # 11 sets, room for 4 blocks, 7 chunks
+    (CHURN, 150, 4, 4, (400, 400, 401), 5),         # 5 sets of 36 groups, room for 1 block
+    (THREE, 1000, 12, 5, (250, 1000), 13),          # three peers: 80 groups a set (84 would split cache lines)
+    (LOSSY, 96, 8, 4, (600,), 0),                   # 2 sets, room for 2 blocks: plain launch
 ])
-def test_relay_matches_oracle(monkeypatch, kw, groups, slot_waves, chunks, launches):
+def test_relay_matches_oracle(monkeypatch, capfd, kw, groups, slot_waves, chunks, launches, sets):
     from oracle.binding import OracleEngine
     from raft_amd import Engine
     monkeypatch.setenv("RAFTGPU_SLOT_WAVES", str(slot_waves))
     monkeypatch.setenv("RAFTGPU_RELAY_CHUNKS", str(chunks))
+    monkeypatch.setenv("RAFTGPU_TRACE_LAUNCH", "1")
     cfg = dict(kw, n_groups=groups)
     o, e = OracleEngine(_abi.make_config(**cfg)), Engine(_abi.make_config(**cfg))
     for n in launches:
@@ -38,3 +39,5 @@ def test_relay_matches_oracle(monkeypatch, kw, groups, slot_waves, chunks, launc
         assert not d, "; ".join(d[:5])
     assert e.counters() == o.counters()
     assert e.counters()["entries_committed"] > 0
+    trace = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("raftgpu: k_tick")]
+    assert len(trace) == len(launches) and all("relay_sets=%d " % sets in ln for ln in trace), trace
