@@ -10,7 +10,10 @@ CASES = {
     "cfg4 16384x7 churn, L=4096, 40000 ticks": (dict(n_groups=16384, n_peers=7, log_cap=4096, seed=4, req_drop_permille=50, reply_drop_permille=50, start_period=10, start_max=3500, start_mode=_abi.START_ALL, churn_period=70, churn_disconnect_permille=200, churn_restart_permille=500, churn_crash_permille=200), 40000),
     "cfg5 131072x3 (one of 8 shards) 1% loss, L=256, 4000 ticks": (dict(n_groups=131072, n_peers=3, log_cap=256, seed=5, req_drop_permille=10, reply_drop_permille=10, start_period=5, start_max=200, group_base=5 * 131072), 4000),
 }
+only = os.environ.get("ONLY")          # e.g. ONLY=cfg4
 for name, (kw, T) in CASES.items():
+    if only and not name.startswith(only):
+        continue
     e = Engine(_abi.make_config(**kw))
     best, last = 1e30, 0.0
     for rep in range(2):
