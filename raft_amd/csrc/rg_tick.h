@@ -125,6 +125,15 @@ __device__ static inline int round_busy(unsigned calledM, unsigned okM, u64 dela
   return busy;
 }
 
+// h % m without a 64-bit division when m fits 16 bits: 16 bits of h at a time, the running remainder stays below m
+__device__ static inline unsigned mod_u64(u64 h, unsigned m) {
+  if (m >= 0x10000u) return (unsigned)(h % (u64)m);
+  const unsigned hi = (unsigned)(h >> 32), lo = (unsigned)h;
+  unsigned r = hi % m;
+  r = ((r << 16) | (lo >> 16)) % m;
+  r = ((r << 16) | (lo & 0xFFFFu)) % m;
+  return r;
+}
 // scheduler slack of the election loop's 50 ms sleep: 0..3 ms, seeded
 __device__ static inline int sleep_slack(u64 key, int p, int now) {
   unsigned h = (unsigned)key ^ ((unsigned)p * 0x9E3779B1u) ^ ((unsigned)now * 0x85EBCA6Bu);
@@ -138,6 +147,9 @@ __device__ static inline int turn_start(u64 key, int tick, int P) {
   return (int)(((h >> 16) * (unsigned)P) >> 16);
 }
 
+#ifndef RG_VERIFY_BATCH
+#define RG_VERIFY_BATCH 48   // applied entries a peer may have unchecked before the wave checks them
+#endif
 #ifndef RG_TICK_WAVES
 #define RG_TICK_WAVES 4   // waves per SIMD the register allocation must allow
 #endif
@@ -421,12 +433,13 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     const bool partNow = c.partPeriod > 0 && run && t == gPartNext;
     const bool churnNow = c.churnPeriod > 0 && run && t >= 1 && t % c.churnPeriod == 0;
     // a Start of a tick the group skipped precedes this tick's control events (otherwise one call below does both)
-    if ((c.partPeriod > 0 || c.churnPeriod > 0) && wave_any(partNow || churnNow)) client_starts(run, t - 1);
+    // (groups without a control event in this tick run theirs up to this tick at the same time)
+    if ((c.partPeriod > 0 || c.churnPeriod > 0) && wave_any(partNow || churnNow)) client_starts(run, (partNow || churnNow) ? t - 1 : t);
     if (partNow) {
       unsigned ep = (unsigned)gPartEpoch;
       r.set(F_SIDE, (stream_hash(key, STREAM_PART, ep, (unsigned)peer + 1) & 1) != 0);
       u64 h = stream_hash(key, STREAM_PART, ep, 0);
-      gPartNext = t + c.partPeriod + (c.partJitter > 0 ? (int)(h % (u64)c.partJitter) : 0);
+      gPartNext = t + c.partPeriod + (c.partJitter > 0 ? (int)mod_u64(h, (unsigned)c.partJitter) : 0);
       gPartEpoch++;
     }
     if (c.churnPeriod > 0 && wave_any(churnNow)) { storesPending = true; verify_applied(churnNow && r.has(F_DEAD)); }   // a restart replays the log
@@ -927,7 +940,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           r.cd(CD_APPLIED) = r.commit;
         }
         // keep the unchecked stretch short, so that a check forced by a rewrite (in the middle of a round) is one step
-        if (wave_any(act && r.commit - lVerified >= 48)) verify_applied(act && r.commit - lVerified >= 48);
+        if (wave_any(act && r.commit - lVerified >= RG_VERIFY_BATCH)) verify_applied(act && r.commit - lVerified >= RG_VERIFY_BATCH);
       }
     }
 
