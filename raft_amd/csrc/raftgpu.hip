@@ -302,12 +302,12 @@ static int run_derive(rg_engine *e) {
 #define RG_MAX_LAUNCH_TICKS 500000
 
 // Ticks per chunk of a relay launch: chunks of at least RG_RELAY_MIN_TICKS, at most RG_RELAY_MAX_CHUNKS of them
-// (a chunk boundary costs a store and a load of the state and a cold start of the LDS rings; measured on 65,536
-// five-peer groups x 20,000 ticks: 67.2 ms plain, 58.1 / 56.4 / 55.4 / 56.4 / 59.7 ms with 2 / 4 / 6 / 12 / 24
-// chunks; a light workload, 131,072 three-peer groups x 4,000 ticks at 1 % loss, loses with 2 chunks: 9.3 ms
-// against 8.5 ms plain).  0: plain launch.
-#define RG_RELAY_MIN_TICKS 3000
-#define RG_RELAY_MAX_CHUNKS 6
+// (a chunk boundary costs a store and a load of the state, a cold start of the LDS rings and an L2 write-back;
+// measured on 65,536 five-peer groups x 20,000 ticks: 67.2 ms plain, 53.6 / 53.4 / 53.5 ms with 6 / 8 / 10 chunks,
+// 59.7 ms with 24; on 131,072 three-peer groups x 4,000 ticks at 1 % loss: 9.1 ms plain, 8.4 / 8.2 / 8.1 ms
+// with 2 / 4 / 6 chunks).  0: plain launch.
+#define RG_RELAY_MIN_TICKS 1000
+#define RG_RELAY_MAX_CHUNKS 8
 static int relay_chunk_ticks(const rg_engine *e, int n_ticks) {
   if (e->relaySets == 0) return 0;
   int k = n_ticks / RG_RELAY_MIN_TICKS;

@@ -81,8 +81,13 @@ __host__ __device__ static inline u64 elem_hash(unsigned peer, unsigned field, u
 __device__ static inline void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
 // per-wave counter block in LDS
-#define RG_CTR_SLOTS 56   // RG_N_COUNTERS public counters, then profiling slots (builds with -DRG_SECTION_COUNTS)
-struct WaveCtr { unsigned c[RG_CTR_SLOTS]; };
+#define RG_CTR_SLOTS 56   // device counter block: RG_N_COUNTERS public counters, then profiling slots of the diagnostic builds
+#if defined(RG_SECTION_COUNTS) || defined(RG_STAMPS)
+#define RG_WAVE_CTR_SLOTS RG_CTR_SLOTS
+#else
+#define RG_WAVE_CTR_SLOTS RG_N_COUNTERS   // a wave's LDS copy holds the public counters only
+#endif
+struct WaveCtr { unsigned c[RG_WAVE_CTR_SLOTS]; };
 #ifdef RG_SECTION_COUNTS
 #define SECTION_COUNT(w, i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&(w)->c[RG_N_COUNTERS + (i)], 1u); } while (0)
 #define SECTION_COUNT_LANE(w, i) atomicAdd(&(w)->c[RG_N_COUNTERS + (i)], 1u)   /* once per calling lane */

@@ -193,6 +193,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
   __shared__ int coldLds[CD_N + 6 + (BYTES ? 2 : 0)][256];   // peer words, 5 group words, the checked-apply cursor, per-lane byte sums
+  __shared__ int churnNext[GPB];                              // per group: its next churn tick (written by all its lanes alike)
   // The last RING entries each peer wrote to its log, and the last RING records of each group, staged in LDS:
   // a follower copies a leader's fresh entries, and every peer applies its fresh entries, without a trip to
   // HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
@@ -238,6 +239,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   const int tEnd = t0 + nticks;
 #define MS_TICK(ms) (((ms) + (RG_TICK_MS - 1)) / RG_TICK_MS)    /* first tick whose time is >= ms (ms >= 0) */
 #define gNextStart coldLds[CD_N + 2][threadIdx.x]
+#define gChurnNext churnNext[gLoc]
   {
     int ns = 0x7fffffff;
     if (c.startPeriod > 0) {
@@ -245,6 +247,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
       if (t0 > c.startFirst) ns += (t0 - c.startFirst + c.startPeriod - 1) / c.startPeriod * c.startPeriod;
     }
     gNextStart = ns;
+    // the group's next churn tick: the first positive multiple of the period in this span or after it (never skipped)
+    gChurnNext = c.churnPeriod > 0 ? ((t0 > 1 ? t0 : 1) + c.churnPeriod - 1) / c.churnPeriod * c.churnPeriod : 0x7fffffff;
   }
   // wake-ups of this lane that lie before tick T and change nothing else
   auto catch_up = [&](int T) {
@@ -306,10 +310,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     }
     cand = G.gmin(cand);
     if (c.partPeriod > 0 && gPartNext < cand) cand = gPartNext;
-    if (c.churnPeriod > 0) {
-      const int nc = ((from > 1 ? from : 1) + c.churnPeriod - 1) / c.churnPeriod * c.churnPeriod;
-      if (nc < cand) cand = nc;
-    }
+    if (c.churnPeriod > 0 && gChurnNext < cand) cand = gChurnNext;
     if (c.startPeriod > 0 && wave_any(startOn && sTick < cand)) {
       // The Start comes before anything else.  It changes no clock but its taker's gate (which then stays the
       // backlog one however many Starts follow), so it is not an event of its own: the group next runs when the
@@ -429,9 +430,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
       asm volatile("" : "+v"(peerL), "+v"(gLocL));
     }
     if (run) catch_up(t);
+    STAMP(9);
     // ------------------------------------------------------------ 1. control
     const bool partNow = c.partPeriod > 0 && run && t == gPartNext;
-    const bool churnNow = c.churnPeriod > 0 && run && t >= 1 && t % c.churnPeriod == 0;
+    const bool churnNow = c.churnPeriod > 0 && run && t == gChurnNext;
     // a Start of a tick the group skipped precedes this tick's control events (otherwise one call below does both)
     // (groups without a control event in this tick run theirs up to this tick at the same time)
     if ((c.partPeriod > 0 || c.churnPeriod > 0) && wave_any(partNow || churnNow)) client_starts(run, (partNow || churnNow) ? t - 1 : t);
@@ -444,6 +446,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     }
     if (c.churnPeriod > 0 && wave_any(churnNow)) { storesPending = true; verify_applied(churnNow && r.has(F_DEAD)); }   // a restart replays the log
     if (churnNow) {                                                  // test_test.go:893-919
+      gChurnNext = t + c.churnPeriod;
       unsigned it = (unsigned)(t / c.churnPeriod);
       u64 h1 = stream_hash(key, STREAM_CHURN, it, 0), h2 = stream_hash(key, STREAM_CHURN, it, 1), h3 = stream_hash(key, STREAM_CHURN, it, 2);
       if ((int)((unsigned)(h1 & 0xFFFFF) % 1000u) < c.churnDisc && peer == (int)((h1 >> 32) % (u64)P)) r.flags &= ~F_CONNECTED;
@@ -461,6 +464,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
         r.flags |= F_DEAD;
       }
     }
+    STAMP(10);
     client_starts(run, t);
 
     STAMP(0);
@@ -963,6 +967,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
       const int ne = next_event(t + 1);
       if (run) tg = ne;
     }
+    STAMP(11);
   }
   client_starts(valid, tEnd - 1);          // Starts and wake-ups the groups skipped towards the end of the launch
   catch_up(tEnd);
@@ -980,6 +985,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 #undef gPartNext
 #undef gRecMax
 #undef gNextStart
+#undef gChurnNext
 #undef MS_TICK
 #undef gPartEpoch
 #undef nextRow
@@ -1019,7 +1025,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
   __shared__ int sItem;
   const int lane = (int)(threadIdx.x & 63);
   WaveCtr *w = &sctr[threadIdx.x >> 6];
-  if (lane < RG_CTR_SLOTS) w->c[lane] = 0;
+  if (lane < RG_WAVE_CTR_SLOTS) w->c[lane] = 0;
   int set = (int)blockIdx.x;
   const int *stIn = nullptr;
   int *stOut = nullptr;
@@ -1051,7 +1057,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     }
   }
   __syncthreads();
-  if (lane < RG_CTR_SLOTS && w->c[lane]) atomicAdd((unsigned long long *)&Sp->counters[lane], (unsigned long long)w->c[lane]);
+  if (lane < RG_WAVE_CTR_SLOTS && w->c[lane]) atomicAdd((unsigned long long *)&Sp->counters[lane], (unsigned long long)w->c[lane]);
 }
 
 #endif
