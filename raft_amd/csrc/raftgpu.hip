@@ -239,7 +239,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   fill_devcfg(e);
   if (e->relaySets > 0) {
     rc = dalloc(e, &e->relay, (size_t)e->relaySets + 1);
-    if (rc == RG_OK) rc = dalloc(e, &e->relayStage, (size_t)e->relaySets * 5 * ((e->gpb + 31) / 32 * 32));
+    if (rc == RG_OK) rc = dalloc(e, &e->relayStage, (size_t)e->relaySets * 7 * ((e->gpb + 31) / 32 * 32));
     if (rc != RG_OK) { free_engine(e); return rc; }
   }
   e->H.relay = e->relay; e->H.relayStage = e->relayStage;

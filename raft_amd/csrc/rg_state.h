@@ -162,7 +162,7 @@ __device__ static inline Rows rows_of(char *arr, const DevCfg &c, int g) {
 struct HotPtrs {
   char *logRows, *snapRows; int *nextIdx, *matchIdx; u64 *applyRec;
   int *relay;                    // relay launches: [0] next item, [1 + set] chunks of the set that are done
-  int *relayStage;               // relay launches: per set, the 5 per-group words of its groups, padded to whole 128-B lines
+  int *relayStage;               // relay launches: per set, 7 words per group (the 5 per-group words, rounds sent before and in the last span), padded to whole 128-B lines
 };
 
 __device__ static inline void ctr_add(WaveCtr *w, int which, unsigned v) { atomicAdd(&w->c[which], v); }

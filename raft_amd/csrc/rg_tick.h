@@ -170,7 +170,29 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   const int wave = (int)(threadIdx.x >> 6);
 
   const int g0 = classA ? set * 4 * c.gwA : c.nbA * 4 * c.gwA + (set - c.nbA) * 4 * c.gwB;   // the set's first group: always < G
-  const int g = g0 + wave * gw + (G.lane / P);
+  constexpr int RING = 4;
+  __shared__ int recIdx[RING][GPB];
+  constexpr int GPBPAD = (GPB + 31) & ~31;
+  // Which of the set's groups the lane works on.  A wave makes as many passes as its busiest group has events, and
+  // how busy a group is changes slowly: from the second span of a launch on, the set's groups are dealt to its
+  // waves in the order of the rounds they sent in the span before (stIn word 6), busiest first, so that busy
+  // groups share waves and the other waves finish early.  (Groups are independent: any dealing gives the same result.)
+  int slot = wave * gw + (G.lane / P);
+  if (stIn) {                                // the same for the whole block
+    const int i = (int)threadIdx.x;
+    if (i < GPB) recIdx[0][i] = (i < 4 * gw && g0 + i < c.G) ? stIn[6 * GPBPAD + i] : (int)0x80000000;   // groups past the set's or the last one: dealt last
+    __syncthreads();
+    if (i < GPB) {
+      const int mine = recIdx[0][i];
+      int rank = 0;
+      for (int j = 0; j < GPB; j++) { const int o = recIdx[0][j]; rank += (o > mine || (o == mine && j < i)) ? 1 : 0; }
+      recIdx[1][rank] = i;
+    }
+    __syncthreads();
+    slot = recIdx[1][slot < GPB ? slot : 0];
+    __syncthreads();                         // recIdx is put to its own use below
+  }
+  const int g = g0 + slot;
   const int peer = G.peer;
   const bool valid = G.inWave && g < c.G;
   const int L = c.L;
@@ -197,11 +219,9 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   // The last RING entries each peer wrote to its log, and the last RING records of each group, staged in LDS:
   // a follower copies a leader's fresh entries, and every peer applies its fresh entries, without a trip to
   // HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
-  constexpr int RING = 4;
   __shared__ int ringIdx[RING][256];
   __shared__ int ringTerm[RING][256];
   __shared__ u64 ringCmd[RING][256];
-  __shared__ int recIdx[RING][GPB];
   __shared__ u64 recVal[RING][GPB];
   const int tid = (int)threadIdx.x;
 #pragma unroll
@@ -213,10 +233,13 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   r.load(*Sp, gl);                       // tail lanes read a valid slot and never write it back
 #define gStartSeq coldLds[CD_N][threadIdx.x]
 #define gPartEpoch coldLds[CD_N + 1][threadIdx.x]
-  constexpr int GPBPAD = (GPB + 31) & ~31;
   gStartSeq = stIn ? stIn[gLoc] : Sp->startSeq[gq]; gPartEpoch = stIn ? stIn[GPBPAD + gLoc] : Sp->partEpoch[gq];
 #define lVerified coldLds[CD_N + 5][threadIdx.x]
   lVerified = r.cd(CD_APPLIED);
+  if (stOut) {                               // rounds the group's peers have sent so far (see the end of the span)
+    const int sent = G.gsum(valid ? r.cd(CD_ROUNDSEQ) : 0);
+    if (valid && peer == 0) stOut[5 * GPBPAD + gLoc] = sent;
+  }
   if constexpr (BYTES) { coldLds[CD_N + 6][threadIdx.x] = 0; coldLds[CD_N + 7][threadIdx.x] = 0; }
 #define gPartNext coldLds[CD_N + 3][threadIdx.x]
 #define gRecMax coldLds[CD_N + 4][threadIdx.x]
@@ -994,6 +1017,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 #undef rOff
   if (G.inWave) r.store(*Sp, gl);
   gfl = G.gor(gfl);
+  if (stOut) {                               // rounds sent in this span: how busy the group is, for the next span's dealing
+    const int sent = G.gsum(valid ? r.cd(CD_ROUNDSEQ) : 0);
+    if (valid && peer == 0) stOut[6 * GPBPAD + gLoc] = sent - stOut[5 * GPBPAD + gLoc];
+  }
   if (valid && peer == 0) {
     Sp->startSeq[g] = startSeqOut; Sp->partNext[g] = partNextOut; Sp->partEpoch[g] = partEpochOut; Sp->recMax[g] = recMaxOut;
     if (stOut) {
@@ -1037,7 +1064,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     const int from = chunk * c.relayChunk;          // < nticks: the grid is exactly the items
     t0 += from;
     nticks = nticks - from < c.relayChunk ? nticks - from : c.relayChunk;
-    constexpr int STAGE = 5 * ((4 * GrpN<P>::GWMAX + 31) & ~31);       // ints per set
+    constexpr int STAGE = 7 * ((4 * GrpN<P>::GWMAX + 31) & ~31);       // ints per set
     stOut = H.relayStage + (size_t)set * STAGE;
     if (chunk > 0) stIn = stOut;
     if (chunk > 0) {
