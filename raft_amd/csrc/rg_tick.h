@@ -171,7 +171,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 
   const int g0 = classA ? set * 4 * c.gwA : c.nbA * 4 * c.gwA + (set - c.nbA) * 4 * c.gwB;   // the set's first group: always < G
   constexpr int RING = 4;
-  __shared__ int recIdx[RING][GPB];
+  __shared__ int ringIdx[RING][256];
   constexpr int GPBPAD = (GPB + 31) & ~31;
   // Which of the set's groups the lane works on.  A wave makes as many passes as its busiest group has events, and
   // how busy a group is changes slowly: from the second span of a launch on, the set's groups are dealt to its
@@ -179,18 +179,20 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   // groups share waves and the other waves finish early.  (Groups are independent: any dealing gives the same result.)
   int slot = wave * gw + (G.lane / P);
   if (stIn) {                                // the same for the whole block
+    int *const rate = &ringIdx[0][0], *const order = &ringIdx[RING / 2][0];   // scratch: the rings are not in use yet
+    static_assert(GPB <= 256 * RING / 2, "scratch of the dealing");
     const int i = (int)threadIdx.x;
-    if (i < GPB) recIdx[0][i] = (i < 4 * gw && g0 + i < c.G) ? stIn[6 * GPBPAD + i] : (int)0x80000000;   // groups past the set's or the last one: dealt last
+    if (i < GPB) rate[i] = (i < 4 * gw && g0 + i < c.G) ? stIn[6 * GPBPAD + i] : (int)0x80000000;   // groups past the set's or the last one: dealt last
     __syncthreads();
     if (i < GPB) {
-      const int mine = recIdx[0][i];
+      const int mine = rate[i];
       int rank = 0;
-      for (int j = 0; j < GPB; j++) { const int o = recIdx[0][j]; rank += (o > mine || (o == mine && j < i)) ? 1 : 0; }
-      recIdx[1][rank] = i;
+      for (int j = 0; j < GPB; j++) { const int o = rate[j]; rank += (o > mine || (o == mine && j < i)) ? 1 : 0; }
+      order[rank] = i;
     }
     __syncthreads();
-    slot = recIdx[1][slot < GPB ? slot : 0];
-    __syncthreads();                         // recIdx is put to its own use below
+    slot = order[slot < GPB ? slot : 0];
+    __syncthreads();                         // the rings are put to their own use below
   }
   const int g = g0 + slot;
   const int peer = G.peer;
@@ -216,16 +218,13 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 
   __shared__ int coldLds[CD_N + 6 + (BYTES ? 2 : 0)][256];   // peer words, 5 group words, the checked-apply cursor, per-lane byte sums
   __shared__ int churnNext[GPB];                              // per group: its next churn tick (written by all its lanes alike)
-  // The last RING entries each peer wrote to its log, and the last RING records of each group, staged in LDS:
-  // a follower copies a leader's fresh entries, and every peer applies its fresh entries, without a trip to
-  // HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
-  __shared__ int ringIdx[RING][256];
+  // The last RING entries each peer wrote to its log, staged in LDS: a follower copies a leader's fresh entries,
+  // and every peer applies its fresh entries, without a trip to HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
   __shared__ int ringTerm[RING][256];
   __shared__ u64 ringCmd[RING][256];
-  __shared__ u64 recVal[RING][GPB];
   const int tid = (int)threadIdx.x;
 #pragma unroll
-  for (int q = 0; q < RING; q++) { ringIdx[q][tid] = -1; if (tid < GPB) recIdx[q][tid] = -1; }
+  for (int q = 0; q < RING; q++) ringIdx[q][tid] = -1;
   __syncthreads();
 #define RING_PUSH(i_, tm_, cm_) do { const int _q = (i_) & (RING - 1); ringIdx[_q][tid] = (i_); ringTerm[_q][tid] = (tm_); ringCmd[_q][tid] = (cm_); } while (0)
   LaneT<lds_int *> r;
@@ -938,7 +937,6 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
               const int i = recLo + 1 + j, q = i & (RING - 1);
               const u64 cmd = ringCmd[q][tid];
               rec(i < L ? i : L - 1) = cmd;
-              if (i > newMax - RING) { recIdx[q][gLoc] = i; recVal[q][gLoc] = cmd; }
             }
           }
           if (sm) {                                   // long or old runs: the whole wave, one entry per lane
@@ -949,13 +947,11 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
               sm &= sm - 1;
               const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), rOffB = (unsigned)__builtin_amdgcn_readlane((int)rOff, src);
               const int lo = __builtin_amdgcn_readlane(recLo, src), n = __builtin_amdgcn_readlane(nRec, src);
-              const int top = __builtin_amdgcn_readlane(newMax, src), gSrc = __builtin_amdgcn_readlane((int)gLoc, src);
               const unsigned col = (unsigned)__builtin_amdgcn_readlane(peer, src);
               for (int j = G.lane; j < n; j += 64) {
-                const int i = lo + 1 + j, ic = i < L ? i : L - 1, q = i & (RING - 1);
+                const int i = lo + 1 + j, ic = i < L ? i : L - 1;
                 const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
                 recBlk[rOffB + (unsigned)ic] = cmd;
-                if (i > top - RING) { recIdx[q][gSrc] = i; recVal[q][gSrc] = cmd; }
               }
             } while (sm);
           }
