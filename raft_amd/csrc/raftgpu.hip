@@ -319,7 +319,10 @@ static int relay_chunk_ticks(const rg_engine *e, int n_ticks) {
 
 static int launch_ticks(rg_engine *e, int n_ticks) {
   hipEvent_t a, b;
-  HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+  HIPCHK(hipEventCreate(&a));
+  if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); return RG_ERR_HIP; }
+  // the pair is owned by pendingEv from here on (collect_events and free_engine destroy it), whatever happens below
+  e->pendingEv.push_back(std::make_pair(a, b));
   DevCfg dc = e->dc;
   int blocks = e->tickBlocks;
   const int chunk = relay_chunk_ticks(e, n_ticks);
@@ -347,7 +350,6 @@ static int launch_ticks(rg_engine *e, int n_ticks) {
 #undef TICK_LAUNCH
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b, e->stream));
-  e->pendingEv.push_back(std::make_pair(a, b));
   e->launches++;
   e->now += n_ticks;
   // group-ticks are counted on the host side of the counter block
