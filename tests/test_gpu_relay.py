@@ -23,6 +23,8 @@ THREE = dict(n_peers=3, log_cap=96, seed=13, req_drop_permille=10, reply_drop_pe
     (CHURN, 150, 4, 4, (400, 400, 401), 5),         # 5 sets of 36 groups, room for 1 block
     (THREE, 1000, 12, 5, (250, 1000), 13),          # three peers: 80 groups a set (84 would split cache lines)
     (LOSSY, 96, 8, 4, (600,), 0),                   # 2 sets, room for 2 blocks: plain launch
+    (LOSSY, 200, 8, 300, (600, 7), 5),              # a boundary (and a new dealing of the groups) every 2 ticks, then every tick
+    (CHURN, 150, 4, 64, (640,), 5),                 # ... with crashes and restarts, every 10 ticks
 ])
 def test_relay_matches_oracle(monkeypatch, capfd, kw, groups, slot_waves, chunks, launches, sets):
     from oracle.binding import OracleEngine
