@@ -51,9 +51,10 @@ def algorithmic_bytes(c, P):
             c["entries_started"] * 12)
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, eng):
     """The CPU checker (a port of the reference's logic to the same lockstep
-    schedule) timed on the host cores, on a bounded sample of the workload."""
+    schedule) timed on the host cores, on a bounded sample of the workload; its
+    result for those groups is then held against the engine's last step."""
     from oracle.binding import OracleEngine
     from raft_amd import _abi
     threads = max(1, min(16, os.cpu_count() or 1))
@@ -73,7 +74,14 @@ def cpu_baseline(args):
     t0 = time.time()
     o1.step(args.ticks)
     dt1 = time.time() - t0
+    import numpy as np
+    n = min(groups, args.groups)
+    same_state = bool(np.array_equal(o.state_hash()[:n], eng.state_hash()[:n]))
+    same_flags = bool(np.array_equal(o.read("gflags")[:n], eng.read("gflags")[:n]))
     return {
+        "check": {"groups": n, "state_digests_equal": same_state, "safety_flags_equal": same_flags,
+                  "note": "per-group digest of every Raft-visible word after the step, engine vs the port; the flags are raised "
+                          "by the reference's own logic under partitions (the port raises the same ones)"},
         "value": c["group_ticks"] / dt, "unit": "group-ticks/s", "cores": threads, "kind": "port",
         "sample": "first %d groups of the workload x %d ticks, groups sharded over %d threads" % (groups, args.ticks, threads),
         "committed_entries_per_s": c["entries_committed"] / dt,
@@ -192,7 +200,7 @@ def main():
         "counters_per_step": counters,
     }
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(args)
+        out["cpu_baseline"] = cpu_baseline(args, eng)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
