@@ -20,7 +20,7 @@ t0 = time.perf_counter()
 accepted = 0
 for i in range(rounds):
     reqs["command"] = (np.arange(G, dtype=np.uint64) << np.uint64(20)) + np.uint64(i + 1)
-    e._check(e._lib.rg_start_batch(e._h, ptr, G), "start_batch")
+    e._check(e._lib.rg_start_batch(e._h, ptr, G), "start_batch")   # what Engine.start_batch_arrays does, without its copies
     accepted += int(np.count_nonzero(reqs["is_leader"]))
     e.step(5)
 e.sync()

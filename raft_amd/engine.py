@@ -169,6 +169,14 @@ class Engine(EngineBase):
         self._check(self._lib.rg_start_batch(self._h, reqs, n), "start_batch")
         return [(r.index, r.term, bool(r.is_leader)) for r in reqs]
 
+    def start_batch_arrays(self, groups, peers, cmds):
+        """rg_start_batch for large batches: numpy arrays in, (index, term, is_leader) arrays out, no Python loop."""
+        reqs = np.zeros(len(groups), dtype=np.dtype([("group", "<i4"), ("peer", "<i4"), ("command", "<u8"), ("index", "<i4"),
+                                                      ("term", "<i4"), ("is_leader", "<i4"), ("pad", "<i4")]))
+        reqs["group"], reqs["peer"], reqs["command"] = groups, peers, cmds
+        self._check(self._lib.rg_start_batch(self._h, reqs.ctypes.data_as(C.POINTER(StartReq)), len(reqs)), "start_batch")
+        return reqs["index"].copy(), reqs["term"].copy(), reqs["is_leader"].astype(bool)
+
     def drain_applied(self, g, p, cap=None):
         cap = cap or self.L
         buf = (ApplyMsgC * cap)()

@@ -106,7 +106,13 @@ def test_start_batch_drain_and_snapshots():
         groups = [int(g) for g in rng.integers(0, 40, size=60)]       # repeats: same-group Starts keep their order
         peers = [int(p) for p in rng.integers(0, 2, size=60)]          # peer 0 leads, peer 1 refuses
         cmds = [int(c) for c in rng.integers(1, 2 ** 62, size=60)]
-        assert o.start_batch(groups, peers, cmds) == e.start_batch(groups, peers, cmds)
+        want = o.start_batch(groups, peers, cmds)
+        assert want == e.start_batch(groups, peers, cmds)
+        if rnd % 2:                                                    # the array form of the same call
+            more = [int(c) + 1 for c in cmds]
+            want = o.start_batch(groups, peers, more)
+            idx, term, lead = e.start_batch_arrays(np.array(groups), np.array(peers), np.array(more, dtype=np.uint64))
+            assert want == [(int(i), int(t), bool(l)) for i, t, l in zip(idx, term, lead)]
         o.step(15)
         e.step(15)
         assert not diff_states(o, e)
