@@ -45,7 +45,7 @@ extern "C" {
 #define RG_CANDIDATE_WINDOW_MS 1000/* timeout while candidate     (:567)        */
 #define RG_TIMEOUT_BASE_MS   500   /* nextRandom(): Intn(600)+500 (:532-534)    */
 #define RG_TIMEOUT_SPAN_MS   600
-#define RG_RPC_WAIT_MS        25   /* a Call without a reply costs the sender this wait (:473,:608) */
+#define RG_RPC_WAIT_MS        25   /* longest a sender waits for one Call (:473,:608); a Call the net fails earlier costs less (labrpc.go:226-229,273-275) */
 #define RG_NET_DELAY_SPAN_MS  27   /* unreliable net: each Call sleeps 0..26 ms (labrpc.go:222)     */
 #define RG_MAX_PEERS           8
 

@@ -22,9 +22,12 @@
  *                    round trip), exactly in the reference's sequential
  *                    fan-out order with its break rules.  The handlers of a
  *                    round all run at the round's tick; the sender is busy for
- *                    the round's duration: 25 ms for every Call without a
- *                    reply (raft.go:473,608) plus the unreliable net's 0..26 ms
- *                    per Call (labrpc.go:222), and its loop resumes after it.
+ *                    the round's duration: per Call, the time until Call
+ *                    returns (the unreliable net's 0..26 ms, labrpc.go:222,
+ *                    for a reply and for a request or reply the net drops,
+ *                    labrpc.go:226-229,273-275) or the 25 ms of the sender's
+ *                    wait (raft.go:473,608), whichever is less; its loop
+ *                    resumes after it.
  *     3. apply     : for p = 0..P-1: the apply loop iteration (10 ms period)
  *     4. check     : one-leader-per-term among connected peers
  *
@@ -233,6 +236,10 @@ static void append_entries(ro_engine *e, ctr_t *c, group_t *g, peer_t *rf, int32
 /* ---------------- network (labrpc.go:216-307) --------------------------- */
 enum { NET_LOST = 0, NET_REPLY_LOST = 1, NET_OK = 2 };
 
+/* *cost: how long the sender's select (raft.go:469-474, 605-609) waits for this Call: until Call returns, true
+ * or false, or 25 ms, whichever comes first.  A request or reply the net drops makes Call return false right
+ * after the net's short delay (labrpc.go:226-229, 273-275); a Call to an unreachable peer returns false after
+ * 0..6999 ms (labrpc.go:290-305: the whole 25 ms here), a long-reordered reply comes after 200 ms or more. */
 static int net_outcome(const ro_engine *e, const group_t *g, int s, int j, uint32_t seq, int32_t *cost, int *wire) {
   const peer_t *a = &g->peer[s], *b = &g->peer[j];
   *cost = RG_RPC_WAIT_MS;
@@ -244,11 +251,12 @@ static int net_outcome(const ro_engine *e, const group_t *g, int s, int j, uint3
   /* the delays of one round come from one hash, 8 bits per target */
   uint64_t delays = stream_hash(g->key, STREAM_NET, 0xFFFF0000u | (uint32_t)s, seq);
   int32_t d = (int32_t)((((delays >> (8 * j)) & 0xFF) * RG_NET_DELAY_SPAN_MS) >> 8);         /* :222, 0..26 */
-  if ((int32_t)((h & 0xFFFFF) % 1000) < cf->req_drop_permille) return NET_LOST;              /* :226 */
+  int32_t back = d < RG_RPC_WAIT_MS ? d : RG_RPC_WAIT_MS;           /* Call returns after d ms; the select gives up at 25 */
+  if ((int32_t)((h & 0xFFFFF) % 1000) < cf->req_drop_permille) { *cost = back; return NET_LOST; }   /* :226-229 */
   *wire = !((int32_t)(((h >> 20) & 0xFFFFF) % 1000) < cf->reply_drop_permille);              /* :273 */
+  if (!*wire) { *cost = back; return NET_REPLY_LOST; }               /* :273-275 */
   if (d >= RG_RPC_WAIT_MS) return NET_REPLY_LOST;                    /* handler runs, the sender has given up */
-  if (!*wire) return NET_REPLY_LOST;
-  if ((int32_t)(((h >> 40) & 0xFFFFF) % 1000) < cf->reply_delay_permille) return NET_REPLY_LOST;  /* :276 */
+  if ((int32_t)(((h >> 40) & 0xFFFFF) % 1000) < cf->reply_delay_permille) return NET_REPLY_LOST;  /* :276-285 */
   *cost = d;
   return NET_OK;
 }

@@ -113,11 +113,19 @@ static int dalloc(rg_engine *e, T **p, size_t n) {
   return RG_OK;
 }
 
+// The network model's three rates: the only words of the device configuration that change after rg_create.
+static void fill_net(rg_engine *e) {
+  DevCfg &d = e->dc; const rg_config &c = e->cfg;
+  d.reqDrop = c.req_drop_permille; d.replyDrop = c.reply_drop_permille; d.replyDelay = c.reply_delay_permille;
+}
+
+// Device configuration and launch layout (packing, relay sets), computed once in rg_create: the relay buffers are
+// sized from it.
 static void fill_devcfg(rg_engine *e) {
   DevCfg &d = e->dc; const rg_config &c = e->cfg;
   d.G = e->G; d.P = e->P; d.L = e->L; d.rowBytes = e->rowBytes; d.cmdOff = e->cmdOff;
   d.groupBase = c.group_base; d.seedKey = sm64(c.seed);
-  d.reqDrop = c.req_drop_permille; d.replyDrop = c.reply_drop_permille; d.replyDelay = c.reply_delay_permille;
+  fill_net(e);
   d.startPeriod = c.start_period; d.startFirst = c.start_first_tick; d.startMax = c.start_max; d.startMode = c.start_mode;
   d.partPeriod = c.part_period; d.partJitter = c.part_jitter;
   d.churnPeriod = c.churn_period; d.churnDisc = c.churn_disconnect_permille; d.churnRestart = c.churn_restart_permille; d.churnCrash = c.churn_crash_permille;
@@ -300,6 +308,9 @@ static int run_derive(rg_engine *e) {
 // The per-wave counters of a launch are 32-bit words in LDS; the fastest of them (wire bytes) can grow by a few
 // thousand per tick, so one launch covers at most this many ticks.
 #define RG_MAX_LAUNCH_TICKS 500000
+// Times are int32 milliseconds on the device (now = tick x RG_TICK_MS, plus timeouts and waits of up to a few
+// seconds): the clock stops here, two simulated hours short of the overflow.
+#define RG_MAX_NOW_TICKS ((long long)(0x7fffffff / RG_TICK_MS) - 720000)
 
 // Ticks per chunk of a relay launch: chunks of at least RG_RELAY_MIN_TICKS, at most RG_RELAY_MAX_CHUNKS of them
 // (a chunk boundary costs a store and a load of the state, a cold start of the LDS rings and an L2 write-back;
@@ -360,7 +371,7 @@ extern "C" int rg_step(rg_engine *e, int32_t n_ticks) {
   LOCK(e);
   if (n_ticks < 0) return RG_ERR_ARG;
   if (n_ticks == 0) return RG_OK;
-  if (e->now + n_ticks > 0x7ffffff0ll) return RG_ERR_RANGE;
+  if (e->now + n_ticks > RG_MAX_NOW_TICKS) return RG_ERR_RANGE;
   int rc = run_derive(e);
   if (rc != RG_OK) return rc;
   while (n_ticks > 0) {
@@ -501,7 +512,7 @@ extern "C" int rg_set_unreliable(rg_engine *e, int32_t a, int32_t b, int32_t d) 
   LOCK(e);
   if (a < 0 || b < 0 || d < 0 || a > 1000 || b > 1000 || d > 1000) return RG_ERR_ARG;
   e->cfg.req_drop_permille = a; e->cfg.reply_drop_permille = b; e->cfg.reply_delay_permille = d;
-  fill_devcfg(e);
+  fill_net(e);
   return RG_OK;
 }
 

@@ -103,25 +103,34 @@ __device__ static inline u64 round_delays(const DevCfg &c, u64 key, int s, unsig
 }
 __device__ static inline int delay_of(u64 delays, int j) { return (int)((((unsigned)(delays >> (8 * j)) & 0xFFu) * (unsigned)RG_NET_DELAY_SPAN_MS) >> 8); }
 // network outcome of one Call, labrpc.go:216-307: 0 lost, 1 handler ran / reply lost or late, 2 round trip;
-// bit 2 (NET_WIRE): the net carried the reply, in time or not, and counted its bytes (labrpc.go:286-290)
+// bit 2 (NET_WIRE): the net carried the reply, in time or not, and counted its bytes (labrpc.go:286-290);
+// bit 3 (NET_FAIL_FAST): the net dropped the request or the reply, so Call returned false right after the
+// net's short delay (labrpc.go:226-229, 273-275) and the sender did not sit out its whole 25 ms wait
 #define NET_WIRE 4
+#define NET_FAIL_FAST 8
 __device__ static inline int net_outcome(const DevCfg &c, u64 key, bool reachable, int s, int j, unsigned seq, u64 delays) {
   if (!reachable) return 0;
   if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) return 2 | NET_WIRE;
   u64 h = stream_hash(key, STREAM_NET, ((unsigned)s << 8) | (unsigned)j, seq);
-  if ((int)((unsigned)(h & 0xFFFFF) % 1000u) < c.reqDrop) return 0;
-  if ((int)((unsigned)((h >> 20) & 0xFFFFF) % 1000u) < c.replyDrop) return 1;
+  if ((int)((unsigned)(h & 0xFFFFF) % 1000u) < c.reqDrop) return 0 | NET_FAIL_FAST;
+  if ((int)((unsigned)((h >> 20) & 0xFFFFF) % 1000u) < c.replyDrop) return 1 | NET_FAIL_FAST;
   if (delay_of(delays, j) >= RG_RPC_WAIT_MS) return 1 | NET_WIRE;   // the handler runs, the sender has given up
   if ((int)((unsigned)((h >> 40) & 0xFFFFF) % 1000u) < c.replyDelay) return 1 | NET_WIRE;
   return 2 | NET_WIRE;
 }
-// How long a round holds its sender: 25 ms for every Call without a reply (raft.go:473,608), else the net's delay.
+// How long a round holds its sender (raft.go:469-474, 605-609 wait for Call's result or 25 ms, whichever comes
+// first): a Call that came back, with a reply (okM) or as a failure the net reported early (failM), costs the
+// net's delay, at most the 25 ms; every other Call the whole 25 ms.
 template <int P>
-__device__ static inline int round_busy(unsigned calledM, unsigned okM, u64 delays) {
+__device__ static inline int round_busy(unsigned calledM, unsigned okM, unsigned failM, u64 delays) {
   int busy = 0;
+  const unsigned backM = okM | failM;
 #pragma unroll
   for (int j = 0; j < P; j++)
-    if ((calledM >> j) & 1u) busy += ((okM >> j) & 1u) ? delay_of(delays, j) : RG_RPC_WAIT_MS;
+    if ((calledM >> j) & 1u) {
+      const int d = delay_of(delays, j);
+      busy += (((backM >> j) & 1u) && d < RG_RPC_WAIT_MS) ? d : RG_RPC_WAIT_MS;
+    }
   return busy;
 }
 
@@ -270,7 +279,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     }
     gNextStart = ns;
     // the group's next churn tick: the first positive multiple of the period in this span or after it (never skipped)
-    gChurnNext = c.churnPeriod > 0 ? ((t0 > 1 ? t0 : 1) + c.churnPeriod - 1) / c.churnPeriod * c.churnPeriod : 0x7fffffff;
+    // (only the group's own lanes write its word: idle lanes carry gLoc 0, another wave's group)
+    if (valid) gChurnNext = c.churnPeriod > 0 ? ((t0 > 1 ? t0 : 1) + c.churnPeriod - 1) / c.churnPeriod * c.churnPeriod : 0x7fffffff;
   }
   // wake-ups of this lane that lie before tick T and change nothing else
   auto catch_up = [&](int T) {
@@ -593,8 +603,9 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
             if (wasLead && d.touch && myPos > sPos && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok), grantM = G.ballot(ok && d.grant);
+          const unsigned failM = G.ballot(called && (outW & NET_FAIL_FAST));
           if constexpr (BYTES) atomicAdd((unsigned *)&coldLds[CD_N + 6][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
-          const int busy = round_busy<P>(calledM, okM, delays);
+          const int busy = round_busy<P>(calledM, okM, failM, delays);
           bool won = false;
           if (wantRV) {
             ctr_add(w, RG_C_RPC_SENT, (unsigned)__popc(calledM));
@@ -848,11 +859,12 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
             }
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
+          const unsigned failM = G.ballot(called && (outW & NET_FAIL_FAST));
           if constexpr (BYTES) {   // wire bytes: summed per target lane in LDS words of its own, added to the counters when the launch ends
             atomicAdd((unsigned *)&coldLds[CD_N + 6][tid], called ? (unsigned)RG_APPEND_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_APPEND_REPLY_BYTES : 0u) : 0u);
             atomicAdd((unsigned *)&coldLds[CD_N + 7][tid], (called && k > 0) ? (unsigned)k : 0u);
           }
-          const int busy = round_busy<P>(calledM, okM, delays);
+          const int busy = round_busy<P>(calledM, okM, failM, delays);
           int rTermB = 0;
           if (wave_any(b < NONE)) rTermB = G.shfl(d.rTerm, b < NONE ? b : 0);
           // Would the commit rule (raft.go:400-416) move commitIndex with the matchIndex row as this round leaves it?

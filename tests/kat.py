@@ -226,7 +226,170 @@ def applied_entry_overwritten(mk):
     assert fl & _abi.FLAG_STATE_MACHINE and n == 1
 
 
+# ---- the seeded election-timeout stream, restated from its definition (docs/LOCKSTEP.md, "Seeded streams") ----
+_M = (1 << 64) - 1
+
+
+def _sm64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M
+    return x ^ (x >> 31)
+
+
+def _timeout_draw(seed, group, peer, draw):
+    """nextRandom() (raft.go:532-534) on the peer's stream: 500 + bits 32..63 of hash(key, 1, peer, draw) % 600."""
+    key = _sm64(_sm64(seed) ^ group)
+    h = _sm64(key ^ (1 << 56) ^ (peer << 32) ^ draw)
+    return 500 + (h >> 32) % 600
+
+
+def _put(e, field, g, p, v):
+    a = e.read(field)
+    a[g, p] = v
+    e.write(field, a)
+
+
+def same_term_vote_request_demotes_leader(mk):
+    """raft.go:208-216: a RequestVote whose term is not below the receiver's sets state = 0 before the vote test,
+    so a leader is demoted by a candidate of its OWN term, although it refuses the vote (it voted for itself)."""
+    e = mk(n_groups=1, n_peers=3, log_cap=16, seed=1)
+    e.step(30)
+    assert e.get_state(0, 0) == (1, True)
+    assert e.request_vote(0, 0, 1, 2, 0, 0) == (1, False)   # same term 1, candidate 2
+    assert (e.read("state")[0, 0], e.read("term")[0, 0], e.read("vote")[0, 0]) == (0, 1, 0)
+    assert e.get_state(0, 0) == (1, False)
+    assert e.start(0, 0, 9) == (-1, 1, False)
+    assert e.read("monalive")[0, 0] == 1                     # the monitor goroutine notices at its next poll
+    e.step(3)
+    assert e.read("monalive")[0, 0] == 0                     # raft.go:396,526-528
+    assert e.read("state")[0].tolist() == [0, 0, 0]
+
+
+def candidate_steps_down_without_adopting_term(mk):
+    """raft.go:618-627: a candidate that sees a higher term in a reply becomes follower with voteFor = -1 but
+    keeps its own currentTerm, ends the round (the peers after it are not called) and draws a new timeout
+    (raft.go:639).  Peer 1 is a candidate at term 3 -> round at term 4; peer 0 is at term 7; peer 2 is never asked."""
+    e = mk(n_groups=1, n_peers=3, log_cap=16, seed=1)
+    _put(e, "term", 0, 0, 7)
+    _put(e, "term", 0, 1, 3)
+    _put(e, "term", 0, 2, 3)
+    _put(e, "state", 0, 1, 1)
+    e.step(1)
+    c = e.counters()
+    assert (c["rv_rounds"], c["rpc_sent"], c["rpc_replied"], c["stepdowns"], c["elections_won"]) == (1, 1, 1, 1, 0)
+    assert e.read("term")[0].tolist() == [7, 4, 3]           # 3 + 1 (raft.go:570); 7 is NOT adopted
+    assert e.read("vote")[0].tolist() == [-1, -1, -1]        # voteFor = me (:575), then -1 (:624); peer 2 untouched
+    assert e.read("state")[0].tolist() == [0, 0, 0]
+    assert (e.read("snapterm")[0, 1], e.read("snapvote")[0, 1]) == (4, -1)   # persist() at :625
+    assert e.read("restart")[0, 1] == 0
+    assert e.read("rngctr")[0, 1] == 2                       # Make (:546) and the draw at :639
+    assert e.read("timeout")[0, 1] == _timeout_draw(1, 0, 1, 1)
+    assert e.read("timer")[0].tolist() == [0, 0, 0]          # the stale-term handler call resets nothing (:205-207)
+
+
+def leader_adopts_term_keeps_vote(mk):
+    """raft.go:479-487: a leader that sees a higher term in an AppendEntries reply becomes follower AT that term,
+    persists, and ends the round; voteFor keeps its old value (itself).  Peer 1 is at term 5, so peer 2 is not
+    called in that round."""
+    e = mk(n_groups=1, n_peers=3, log_cap=16, seed=1)
+    e.step(30)
+    assert e.get_state(0, 0) == (1, True) and e.read("vote")[0, 0] == 0
+    _put(e, "term", 0, 1, 5)
+    _put(e, "hbtimer", 0, 0, -1000)                          # the gate of raft.go:421 opens at the next poll
+    before = e.counters()
+    e.step(2)
+    c = e.counters()
+    assert c["ae_rounds"] - before["ae_rounds"] == 1
+    assert c["rpc_sent"] - before["rpc_sent"] == 1           # break at :487: peer 2 is not called
+    assert c["stepdowns"] - before["stepdowns"] == 1
+    assert (e.read("term")[0, 0], e.read("vote")[0, 0], e.read("state")[0, 0]) == (5, 0, 0)
+    assert (e.read("snapterm")[0, 0], e.read("snapvote")[0, 0]) == (5, 0)
+    assert e.read("term")[0, 2] == 1
+    assert e.read("monalive")[0, 0] == 0                     # next loop iteration: not leader, exit (:526-528)
+
+
+def votes_are_counted_per_reply(mk):
+    """raft.go:585-616: all RequestVote RPCs of a round decode into ONE reply struct and gob leaves a field
+    alone when the wire value is zero (labgob.go:116-121), so VoteGranted is cleared by hand after it is
+    counted (:615).  One grant followed by three refusals is therefore 2 votes of 5, not 5: no leader, and the
+    candidate is marked to retry (restart, :660)."""
+    e = mk(n_groups=1, n_peers=5, log_cap=16, seed=1)
+    _put(e, "state", 0, 0, 1)                                # candidate; round at term 1
+    for p in (2, 3, 4):                                      # already voted for peer 4 in term 1
+        _put(e, "term", 0, p, 1)
+        _put(e, "vote", 0, p, 4)
+    e.step(1)
+    c = e.counters()
+    assert (c["rv_rounds"], c["rpc_sent"], c["rpc_delivered"], c["rpc_replied"], c["elections_won"]) == (1, 4, 4, 4, 0)
+    assert e.read("vote")[0].tolist() == [0, 0, 4, 4, 4]
+    assert e.read("term")[0].tolist() == [1, 1, 1, 1, 1]
+    assert (e.read("state")[0, 0], e.read("restart")[0, 0], e.read("timeout")[0, 0]) == (1, 1, 1000)
+    assert e.read("state")[0, 4] == 0                        # raft.go:216
+
+
+def late_vote_replies_are_lost(mk):
+    """raft.go:605-610: a reply that comes after the 25 ms wait is never looked at (in the reference it would
+    land in the shared struct later: a data race).  With every reply long-delayed (labrpc.go:276-285) all four
+    voters grant -- their handlers ran -- and the candidate counts only itself; it waited 4 x 25 ms."""
+    e = mk(n_groups=1, n_peers=5, log_cap=16, seed=1, reply_delay_permille=1000)
+    _put(e, "state", 0, 0, 1)
+    e.step(1)
+    c = e.counters()
+    assert (c["rpc_sent"], c["rpc_delivered"], c["rpc_replied"], c["elections_won"]) == (4, 4, 0, 0)
+    assert e.read("vote")[0].tolist() == [0, 0, 0, 0, 0]
+    assert (e.read("state")[0, 0], e.read("restart")[0, 0]) == (1, 1)
+    assert 150 <= e.read("elnext")[0, 0] <= 153              # 4 x 25 ms of waits, then the 50 ms sleep (+ slack)
+
+
+def failed_candidate_retries_same_term(mk):
+    """raft.go:569-573, 660: a candidate that neither won nor stepped down sets restart and its next round does
+    NOT increment currentTerm.  Peer 0 (timeout 0 at boot, raft.go:545) is cut off: it turns candidate at its
+    second loop iteration, runs a round every 100 ms + 50 ms sleep, and stays at term 1 for ever; the round
+    sets timeout = 1000 (:567) without a draw."""
+    e = mk(n_groups=1, n_peers=3, log_cap=16, seed=1)
+    e.set_connected(0, 0, False)
+    e.step(8)
+    assert (e.read("state")[0, 0], e.read("term")[0, 0], e.read("rngctr")[0, 0]) == (1, 0, 1)   # :557-561, one draw
+    e.step(12)
+    assert (e.read("term")[0, 0], e.read("restart")[0, 0], e.read("roundseq")[0, 0]) == (1, 1, 1)
+    e.step(180)
+    rounds = e.read("roundseq")[0, 0]
+    assert rounds >= 10
+    assert (e.read("term")[0, 0], e.read("state")[0, 0], e.read("restart")[0, 0]) == (1, 1, 1)
+    assert (e.read("timeout")[0, 0], e.read("rngctr")[0, 0]) == (1000, 1)
+    assert e.read("vote")[0, 0] == 0
+    return e
+
+
+def rng_draw_points(mk):
+    """nextRandom() is called at Make unless (term 0, peer 0) (raft.go:545-547), on follower -> candidate (:561)
+    and after a round that ended in a step-down (:639); the round itself sets timeout = 1000 without a draw
+    (:567), winning draws nothing, and a candidate demoted by a HANDLER keeps timeout 1000 (the loop's local
+    variable is only redrawn at :561/:639)."""
+    e = mk(n_groups=1, n_peers=3, log_cap=16, seed=1)
+    assert e.read("rngctr")[0].tolist() == [0, 1, 1]
+    assert e.read("timeout")[0].tolist() == [0, _timeout_draw(1, 0, 1, 0), _timeout_draw(1, 0, 2, 0)]
+    e.step(30)                                               # peer 0: candidate (draw), round (no draw), wins (no draw)
+    assert e.get_state(0, 0) == (1, True)
+    assert e.read("rngctr")[0].tolist() == [1, 1, 1]
+    assert e.read("timeout")[0].tolist() == [1000, _timeout_draw(1, 0, 1, 0), _timeout_draw(1, 0, 2, 0)]
+    e.restart(0, 1)                                          # Make at term 1: one draw (:546)
+    assert e.read("rngctr")[0, 1] == 2 and e.read("timeout")[0, 1] == _timeout_draw(1, 0, 1, 1)
+    # a candidate demoted by AppendEntries (raft.go:280): no draw, timeout stays 1000
+    e = failed_candidate_retries_same_term(mk)
+    e.set_connected(0, 0, True)
+    for _ in range(300):
+        e.step(1)
+        if e.read("state")[0, 0] == 0:
+            break
+    assert e.read("state")[0, 0] == 0
+    assert (e.read("timeout")[0, 0], e.read("rngctr")[0, 0]) == (1000, 1)
+
+
 CASES = {f.__name__: f for f in (
     boot_and_three_starts, conflict_reply, append_truncates_unconditionally, leader_backoff, commit_rule,
     vote_compares_commit_index, restore_repersists_one_entry, start_on_isolated_leader, stop_rule,
-    applied_entry_overwritten)}
+    applied_entry_overwritten, same_term_vote_request_demotes_leader, candidate_steps_down_without_adopting_term,
+    leader_adopts_term_keeps_vote, votes_are_counted_per_reply, late_vote_replies_are_lost,
+    failed_candidate_retries_same_term, rng_draw_points)}

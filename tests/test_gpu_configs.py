@@ -109,6 +109,15 @@ def test_cfg5_shard_of_a_million_groups():
     _every_group(CFG5, 131072, 4000, 16384, engine_base=5 * 131072)
 
 
+def test_target_shard_131072x5_every_group():
+    """One rank's share of the target job -- 1,048,576 five-peer groups on 8 GPUs = 131,072 x 5 per GPU -- under the
+    benchmark workload (10 % + 10 % loss, rolling partitions, 1000 entries, 20,000 ticks), as rank 5 of 8."""
+    e = _every_group(CFG3, 131072, 20000, 8192, engine_base=5 * 131072)
+    c = e.counters()
+    assert c["group_ticks"] == 131072 * 20000
+    assert c["entries_committed"] > 0.9 * 131072 * 1000
+
+
 def test_cfg4_full_size_every_group():
     """16,384 seven-peer groups, 4096-entry logs, crash / restart churn."""
     e = _every_group(CFG4, 16384, 40000, 2048)
