@@ -56,6 +56,7 @@ extern "C" {
 #define RG_ERR_NOMEM    -3
 #define RG_ERR_RANGE    -4   /* group / peer / index out of range             */
 #define RG_ERR_STATE    -5   /* verb not legal in the peer's current state    */
+#define RG_ERR_SCRATCH  -6   /* rg_step_noalloc: the engine needs more than the fixed device scratch */
 
 /* ---- peer roles (Raft.state, src/raft/raft.go:82) ----------------------- */
 #define RG_FOLLOWER  0
@@ -186,6 +187,17 @@ int rg_set_stream(rg_engine *e, void *hip_stream);
  * kernel launch; state stays resident in HBM between calls.  Asynchronous on
  * the engine's stream; rg_sync waits. */
 int rg_step(rg_engine *e, int32_t n_ticks);
+/* rg_step without any allocation.  No counterpart in the reference: it is for callers that cannot allocate
+ * device or host memory while they step -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  Same kernels and same result as rg_step; the work queue and staging area that launches of
+ * more groups than the chip holds at once need live in a fixed 8 MiB device array (RG_NOALLOC_SCRATCH_BYTES,
+ * one copy per GPU, held until the process ends) instead of the buffers rg_create allocated; the launch is not
+ * timed (rg_step_time_ms does not see it).  Engines too large for the array (more than about 4,600 sets of
+ * 4 wavefronts' groups, e.g. 220,000 five-peer groups) get RG_ERR_SCRATCH and nothing is launched; engines that
+ * fit the chip at once use no scratch and are never refused.  All engines on one GPU share the array: calls
+ * that overlap in time on one GPU (different engines on different streams) race; serialise them. */
+#define RG_NOALLOC_SCRATCH_BYTES (8u << 20)
+int rg_step_noalloc(rg_engine *e, int32_t n_ticks);
 int rg_sync(rg_engine *e);
 int rg_now(rg_engine *e, int64_t *tick);
 /* Wall time (ms) of the kernels launched by rg_step so far, from HIP events

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("RAFTGPU_LIB") or os.path.join(HERE, "lib", "libraftgp
 # ---- constants mirrored from include/raftgpu.h ---------------------------
 TICK_MS = 10
 MAX_PEERS = 8
-OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_RANGE, ERR_STATE = 0, -1, -2, -3, -4, -5
+OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_RANGE, ERR_STATE, ERR_SCRATCH = 0, -1, -2, -3, -4, -5, -6
 FOLLOWER, CANDIDATE, LEADER = 0, 1, 2
 
 FLAG_ELECTION_SAFETY = 0x01
@@ -108,7 +108,7 @@ def make_config(**kw):
 # every symbol include/raftgpu.h declares
 EXPORTS = [
     "rg_device_count", "rg_version", "rg_strerror", "rg_create", "rg_destroy", "rg_reset", "rg_set_stream",
-    "rg_step", "rg_sync", "rg_now", "rg_step_time_ms", "rg_start", "rg_start_batch", "rg_get_state",
+    "rg_step", "rg_step_noalloc", "rg_sync", "rg_now", "rg_step_time_ms", "rg_start", "rg_start_batch", "rg_get_state",
     "rg_set_connected", "rg_set_side", "rg_crash", "rg_restart", "rg_set_unreliable", "rg_drain_applied",
     "rg_snapshot_export", "rg_snapshot_import", "rg_rpc_request_vote", "rg_rpc_append_entries",
     "rg_read_state", "rg_write_state", "rg_state_hash", "rg_counters", "rg_rpc_bytes", "rg_safety_check", "rg_safety_flags",
@@ -138,6 +138,7 @@ def load_library(path=None):
         "rg_reset": ([vp], C.c_int),
         "rg_set_stream": ([vp, vp], C.c_int),
         "rg_step": ([vp, i32], C.c_int),
+        "rg_step_noalloc": ([vp, i32], C.c_int),
         "rg_sync": ([vp], C.c_int),
         "rg_now": ([vp, P(i64)], C.c_int),
         "rg_step_time_ms": ([vp, P(C.c_double), P(i64)], C.c_int),

@@ -38,6 +38,28 @@ typedef unsigned long long u64;
 #include "rg_tick.h"
 #include "rg_kernels.h"
 
+// ---------------------------------------------------------------- fixed device scratch of rg_step_noalloc
+// The relay queue and staging area of a relay launch (see k_tick) for callers that may not allocate.  One copy
+// per GPU, held until the process ends.  The name below is a host-side stand-in, not a device address: host code
+// uses the per-device address hipGetSymbolAddress returns (scratch_of), never the name.
+#define RG_SCRATCH_INTS (RG_NOALLOC_SCRATCH_BYTES / 4u)
+static __device__ __align__(256) int scratch[RG_SCRATCH_INTS];
+#define RG_MAX_DEVICES 64
+static int *g_scratchPtr[RG_MAX_DEVICES];               // per device: address of that device's copy of scratch
+static std::mutex g_scratchMu;
+// Address of the current device's copy; looked up once per device, with that device current.
+static int scratch_of(int device, int **out) {
+  if (device < 0 || device >= RG_MAX_DEVICES) return RG_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g_scratchMu);
+  if (!g_scratchPtr[device]) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return RG_ERR_HIP;
+    g_scratchPtr[device] = (int *)p;
+  }
+  *out = g_scratchPtr[device];
+  return RG_OK;
+}
+
 // ---------------------------------------------------------------- host side
 struct rg_engine {
   rg_config cfg;
@@ -47,6 +69,7 @@ struct rg_engine {
   int relaySets, relayGw;   // sets of a relay launch and groups per wave in them; 0 when the groups fit the chip at once
   int *relay;           // device: [0] next item, [1 + set] chunks done
   int *relayStage;      // device: per-group words in transit between the blocks of a relay launch
+  int *scratchDev;      // this device's copy of the fixed scratch array (rg_step_noalloc)
   long long nLanes;
   DevPtrs S;
   DevPtrs *dS;          // device copy of S: the tick kernel reads the cold pointers through it
@@ -79,6 +102,7 @@ extern "C" const char *rg_strerror(int st) {
   case RG_ERR_NOMEM: return "out of memory";
   case RG_ERR_RANGE: return "group/peer/index out of range";
   case RG_ERR_STATE: return "illegal in this state";
+  case RG_ERR_SCRATCH: return "engine too large for the fixed device scratch of rg_step_noalloc";
   default: return "unknown status";
   }
 }
@@ -225,7 +249,8 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (hipStreamCreateWithFlags(&e->ownStream, hipStreamNonBlocking) != hipSuccess) { delete e; return RG_ERR_HIP; }
   e->stream = e->ownStream;
   DevPtrs &S = e->S;
-  int rc = RG_OK;
+  int rc = scratch_of(cfg->device, &e->scratchDev);
+  if (rc != RG_OK) { hipStreamDestroy(e->ownStream); delete e; return rc; }
   int **i32s[] = {&S.term, &S.vote, &S.flags, &S.commit, &S.applied, &S.logLen, &S.timer, &S.timeout, &S.hbTimer, &S.elNext, &S.monNext,
                   &S.rngCtr, &S.roundSeq, &S.snapTerm, &S.snapVote, &S.snapLen, &S.snapSync, &S.lastTerm, &S.firstOwn, &S.commitTerm};
   for (int **p : i32s) if (rc == RG_OK) rc = dalloc(e, p, (size_t)e->nLanes);
@@ -328,27 +353,24 @@ static int relay_chunk_ticks(const rg_engine *e, int n_ticks) {
   return (n_ticks + k - 1) / k;
 }
 
-static int launch_ticks(rg_engine *e, int n_ticks) {
-  hipEvent_t a, b;
-  HIPCHK(hipEventCreate(&a));
-  if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); return RG_ERR_HIP; }
-  // the pair is owned by pendingEv from here on (collect_events and free_engine destroy it), whatever happens below
-  e->pendingEv.push_back(std::make_pair(a, b));
+// One launch of the tick kernel.  relay / relayStage: the queue and staging area a relay launch uses.
+static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage) {
   DevCfg dc = e->dc;
+  HotPtrs H = e->H;
+  H.relay = relay; H.relayStage = relayStage;
   int blocks = e->tickBlocks;
   const int chunk = relay_chunk_ticks(e, n_ticks);
   if (chunk > 0) {
     dc.relaySets = e->relaySets; dc.relayChunk = chunk;
     dc.nbA = e->relaySets; dc.gwA = e->relayGw;
     blocks = e->relaySets * ((n_ticks + chunk - 1) / chunk);   // one block per item
-    HIPCHK(hipMemsetAsync(e->relay, 0, (size_t)(e->relaySets + 1) * sizeof(int), e->stream));
+    HIPCHK(hipMemsetAsync(relay, 0, (size_t)(e->relaySets + 1) * sizeof(int), e->stream));
   }
   if (getenv("RAFTGPU_TRACE_LAUNCH")) fprintf(stderr, "raftgpu: k_tick ticks=%d blocks=%d relay_sets=%d relay_chunk=%d groups_per_wave=%d\n", n_ticks, blocks, dc.relaySets, dc.relayChunk, dc.gwA);
-  HIPCHK(hipEventRecord(a, e->stream));
   const DevPtrs *dS = e->dS;
 #define TICK_LAUNCH(PEERS) do { \
-    if (dc.acctBytes) hipLaunchKernelGGL((k_tick<PEERS, true>), dim3(blocks), dim3(256), 0, e->stream, dS, e->H, dc, (int)e->now, n_ticks); \
-    else hipLaunchKernelGGL((k_tick<PEERS, false>), dim3(blocks), dim3(256), 0, e->stream, dS, e->H, dc, (int)e->now, n_ticks); } while (0)
+    if (dc.acctBytes) hipLaunchKernelGGL((k_tick<PEERS, true>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
+    else hipLaunchKernelGGL((k_tick<PEERS, false>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)
   switch (e->P) {
   case 2: TICK_LAUNCH(2); break;
   case 3: TICK_LAUNCH(3); break;
@@ -360,6 +382,18 @@ static int launch_ticks(rg_engine *e, int n_ticks) {
   }
 #undef TICK_LAUNCH
   HIPCHK(hipGetLastError());
+  return RG_OK;
+}
+
+static int launch_ticks(rg_engine *e, int n_ticks) {
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a));
+  if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); return RG_ERR_HIP; }
+  // the pair is owned by pendingEv from here on (collect_events and free_engine destroy it), whatever happens below
+  e->pendingEv.push_back(std::make_pair(a, b));
+  HIPCHK(hipEventRecord(a, e->stream));
+  int rc = launch_kernel(e, n_ticks, e->relay, e->relayStage);
+  if (rc != RG_OK) return rc;
   HIPCHK(hipEventRecord(b, e->stream));
   e->launches++;
   e->now += n_ticks;
@@ -379,6 +413,32 @@ extern "C" int rg_step(rg_engine *e, int32_t n_ticks) {
     const int n = n_ticks < RG_MAX_LAUNCH_TICKS ? n_ticks : RG_MAX_LAUNCH_TICKS;
     rc = launch_ticks(e, n);
     if (rc != RG_OK) return rc;
+    n_ticks -= n;
+  }
+  return RG_OK;
+}
+
+// Words of the relay queue (next item + one per set) rounded up to whole 128-byte lines, and of the staging area.
+static size_t relay_queue_ints(const rg_engine *e) { return ((size_t)e->relaySets + 1 + 31) / 32 * 32; }
+static size_t relay_stage_ints(const rg_engine *e) { return (size_t)e->relaySets * 7 * ((e->gpb + 31) / 32 * 32); }
+
+// rg_step for callers that may not allocate: the same kernels, with the relay queue and staging area in the fixed
+// device array instead of the buffers rg_create allocated, no events (the launch is not timed), no host or device
+// allocation of any kind.
+extern "C" int rg_step_noalloc(rg_engine *e, int32_t n_ticks) {
+  LOCK(e);
+  if (n_ticks < 0) return RG_ERR_ARG;
+  if (n_ticks == 0) return RG_OK;
+  if (e->now + n_ticks > RG_MAX_NOW_TICKS) return RG_ERR_RANGE;
+  if (e->relaySets > 0 && relay_queue_ints(e) + relay_stage_ints(e) > (size_t)RG_SCRATCH_INTS) return RG_ERR_SCRATCH;
+  int rc = run_derive(e);
+  if (rc != RG_OK) return rc;
+  int *const queue = e->scratchDev, *const stage = e->scratchDev + relay_queue_ints(e);
+  while (n_ticks > 0) {
+    const int n = n_ticks < RG_MAX_LAUNCH_TICKS ? n_ticks : RG_MAX_LAUNCH_TICKS;
+    rc = launch_kernel(e, n, queue, stage);      // clears the queue words it uses; the staging area is written before it is read
+    if (rc != RG_OK) return rc;
+    e->now += n;
     n_ticks -= n;
   }
   return RG_OK;

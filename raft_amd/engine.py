@@ -145,6 +145,10 @@ class Engine(EngineBase):
     def reset(self):
         self._check(self._lib.rg_reset(self._h), "reset")
 
+    def step_noalloc(self, n_ticks=1):
+        """rg_step through the entry point that allocates nothing (fixed device scratch)."""
+        self._check(self._lib.rg_step_noalloc(self._h, int(n_ticks)), "step_noalloc")
+
     def sync(self):
         self._check(self._lib.rg_sync(self._h), "sync")
 
