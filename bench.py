@@ -14,6 +14,8 @@ collective is one all-reduce of counters and safety flags per step.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` without a launcher starts its own N rank processes (one per GPU) and prints rank 0's line.
 """
 import argparse
 import json
@@ -25,7 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak
+HBM_MEASURED_PEAK_GBS = 6290.0   # best streaming copy measured on the part
 
 
 def workload_config(args, rank):
@@ -40,15 +43,43 @@ def workload_config(args, rank):
 
 
 def algorithmic_bytes(c, P):
-    """Bytes the lockstep model has to move, from the engine's event counters:
-    the 40 B scalar block of every peer once per tick, plus per event: a vote
-    request 64 B, an AppendEntries 124 B + 24 B per entry, one commit scan
-    (4P+4 B) per replication round, 24 B per applied entry, 12 B per persist
+    """Bytes the lockstep model has to move, from the engine's event counters, as (floor, events): the floor is
+    the 40 B scalar block of every peer once per tick; per event: a vote request 64 B, an AppendEntries 124 B +
+    24 B per entry, one commit scan (4P+4 B) per replication round, 24 B per applied entry, 12 B per persist
     header and per newly persisted entry, 12 B per appended entry."""
     rv_delivered = c["rpc_delivered"] - c["ae_delivered"]
-    return (c["group_ticks"] * 40 * P + rv_delivered * 64 + c["ae_delivered"] * 124 + c["entries_replicated"] * 24 +
-            c["ae_rounds"] * (4 * P + 4) + c["entries_applied"] * 24 + c["persists"] * 12 + c["persist_entries"] * 12 +
-            c["entries_started"] * 12)
+    floor = c["group_ticks"] * 40 * P
+    events = (rv_delivered * 64 + c["ae_delivered"] * 124 + c["entries_replicated"] * 24 +
+              c["ae_rounds"] * (4 * P + 4) + c["entries_applied"] * 24 + c["persists"] * 12 + c["persist_entries"] * 12 +
+              c["entries_started"] * 12)
+    return floor, events
+
+
+def launch_ranks(n, script=None, argv=None, check_devices=True):
+    """`--gpus N` without a launcher: N fresh rank processes of this script, one per GPU, started before anything
+    here has touched a GPU; rank 0's output is passed on.  Returns the exit status for this process."""
+    import socket
+    import subprocess
+    if check_devices:
+        import torch
+        have = torch.cuda.device_count()          # counts devices without initialising one
+        if have < n:
+            raise SystemExit("--gpus %d: this host shows %d GPU(s)" % (n, have))
+    script = script or os.path.abspath(__file__)
+    argv = sys.argv[1:] if argv is None else argv
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def cpu_baseline(args, eng):
@@ -106,7 +137,11 @@ def main():
     ap.add_argument("--launch-ticks", type=int, default=0, help="ticks per kernel launch (0 = the whole schedule)")
     ap.add_argument("--cpu-groups", type=int, default=16384)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="run the N ranks on GPU 0 over gloo: checks the multi-rank path on a 1-GPU box; its line is marked and is no measurement")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, check_devices=not args.rehearse_on_one_gpu))
 
     import torch
     import torch.distributed as dist
@@ -117,11 +152,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
+    red_dev = torch.device("cpu") if args.rehearse_on_one_gpu else torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    eng = Engine(workload_config(args, rank))
+    cfg = workload_config(args, rank)
+    cfg.device = local
+    eng = Engine(cfg)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     launch = args.launch_ticks or args.ticks
     from raft_amd.distributed import all_reduce_summary
@@ -140,7 +183,7 @@ def main():
             done += n
         # counters and safety flags: the only cross-GPU exchange of the path
         fl, nfl = eng.safety_flags()
-        return all_reduce_summary(eng.counters(), fl, nfl, torch.device("cuda", local))
+        return all_reduce_summary(eng.counters(), fl, nfl, red_dev)
 
     for _ in range(args.warmup):
         one_step()
@@ -153,7 +196,7 @@ def main():
     dt = time.perf_counter() - t0
     ms1, n1 = eng.step_time_ms()
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -166,13 +209,18 @@ def main():
     launches = max(1, n1 - n0)
     kernel_ms = (ms1 - ms0) / launches
     launches_per_step = (args.ticks + launch - 1) // launch
-    bytes_per_launch = algorithmic_bytes(local_c, args.peers) / launches_per_step
+    floor_bytes, event_bytes = (b / launches_per_step for b in algorithmic_bytes(local_c, args.peers))
+    bytes_per_launch = floor_bytes + event_bytes
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch from hardware counters cannot be read from inside this process: they come from separate
+    # rocprofv3 --pmc passes over this same command (profiles/run_pmc.sh), stored next to the profiles.
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc) and launch == 20000 and args.groups == 65536:   # the counters were collected on the default launch only
+    if os.path.exists(pmc) and launch == 20000 and args.groups == 65536 and args.peers == 5:   # collected on the default launch only
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc))
+            traffic = rec.get("hbm_bytes_per_launch")
+            traffic_source = "profiles/pmc_traffic.json (%s): not measured in this run" % rec.get("collected", "rocprofv3 --pmc passes of this command")
         except Exception:
             traffic = None
 
@@ -191,14 +239,23 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "k_tick", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": "k_tick", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+            # the two parts of the algorithmic figure: the per-tick floor (40 B x peers x group-ticks), which a fused
+            # launch never moves, and the bytes of the counted events; and the same rate against the measured peak
+            "floor_bytes": floor_bytes, "event_bytes": event_bytes,
+            "frac_event_bytes": event_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "measured_peak": HBM_MEASURED_PEAK_GBS, "frac_of_measured_peak": achieved / HBM_MEASURED_PEAK_GBS,
             "mode": ("fused: peer scalars stay in registers and LDS within a launch of %d ticks (cut into relay chunks of "
-                     "at least 3,000 ticks when the groups exceed what the chip holds at once)" % launch) if launch > 1
+                     "at least 1,000 ticks, at most 8, when the groups exceed what the chip holds at once)" % launch) if launch > 1
                     else "streamed: every peer's state is loaded and stored once per tick",
         },
         "safety_flags": flags, "flagged_groups": flagged_groups,
         "counters_per_step": counters,
     }
+    if args.rehearse_on_one_gpu:
+        out["rehearsal"] = "all %d ranks shared GPU 0 over gloo: not a measurement" % world
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args, eng)
     elif rank == 0:
