@@ -56,6 +56,7 @@ extern "C" {
 #define RG_ERR_NOMEM    -3
 #define RG_ERR_RANGE    -4   /* group / peer / index out of range             */
 #define RG_ERR_STATE    -5   /* verb not legal in the peer's current state    */
+#define RG_ERR_OVERRUN  -7   /* rg_drain_applied: ApplyMsgs were overwritten in the ring before they were drained */
 #define RG_ERR_SCRATCH  -6   /* rg_step_noalloc: the engine needs more than the fixed device scratch */
 
 /* ---- peer roles (Raft.state, src/raft/raft.go:82) ----------------------- */
@@ -149,7 +150,11 @@ typedef struct rg_config {
   int32_t  churn_crash_permille;
   /* wire-byte accounting for rg_rpc_bytes (RG_C_RPC_FIXED_BYTES, RG_C_AE_ENTRIES_SENT): off by default */
   int32_t  account_bytes;
-  int32_t  reserved[2];
+  /* applyCh for host readers (rg_drain_applied): ApplyMsgs each peer may have pending between two drains, 0 = the
+   * engine keeps no ring (device-generated workloads, whose tester side runs on the device).  16 bytes per
+   * message, n_groups x n_peers x apply_ring_cap messages of device memory. */
+  int32_t  apply_ring_cap;
+  int32_t  reserved[1];
 } rg_config;
 
 typedef struct rg_engine rg_engine;
@@ -223,8 +228,12 @@ int rg_restart(rg_engine *e, int32_t group, int32_t peer);
 int rg_set_unreliable(rg_engine *e, int32_t req_drop_permille,
                       int32_t reply_drop_permille, int32_t reply_delay_permille);
 
-/* applyCh (raft.go:672-688): copies the ApplyMsgs the peer emitted since the
- * last drain (after a restart the replay from index 1) into buf. */
+/* applyCh (raft.go:672-688): copies the ApplyMsgs the (group, peer) slot emitted since the last drain into buf,
+ * in the order and with the commands of the moment they were emitted (raft.go:680-684): an entry applied and later
+ * overwritten in the log is delivered as it was applied, and a peer restarted in between (by rg_restart or by the
+ * device-side churn) delivers its replay from index 1 after what its predecessor emitted.  Needs
+ * rg_config.apply_ring_cap > 0 (else RG_ERR_STATE).  If more than apply_ring_cap messages were emitted since the
+ * last drain the oldest are gone: the call returns RG_ERR_OVERRUN once, with the messages still there. */
 int rg_drain_applied(rg_engine *e, int32_t group, int32_t peer,
                      rg_apply_msg *buf, int64_t cap, int64_t *n_out);
 

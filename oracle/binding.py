@@ -8,8 +8,8 @@ import os
 import subprocess
 
 from raft_amd import _abi
-from raft_amd._abi import AppendArgs, AppendReply, VoteArgs, VoteReply, Config
-from raft_amd.engine import EngineBase
+from raft_amd._abi import AppendArgs, AppendReply, ApplyMsgC, VoteArgs, VoteReply, Config
+from raft_amd.engine import EngineBase, RaftGpuError
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libraft_oracle.so")
@@ -51,6 +51,7 @@ def load(path=None):
         "ro_safety_check": ([vp], C.c_int), "ro_safety_flags": ([vp, P(C.c_uint32)], C.c_int),
         "ro_snapshot_export": ([vp, i32, i32, vp, i64, P(i64)], C.c_int),
         "ro_snapshot_import": ([vp, i32, i32, vp, i64], C.c_int),
+        "ro_drain_applied": ([vp, i32, i32, P(ApplyMsgC), i64, P(i64)], C.c_int),
         "ro_leader_backoff": ([vp, i32, i32, i32, i32, i32], i32),
         "ro_commit_rule": ([vp, i32, i32], i32),
     }
@@ -72,7 +73,6 @@ class OracleEngine(EngineBase):
         self._h = self._lib.ro_create(C.byref(self.cfg))
         if not self._h:
             raise ValueError("ro_create rejected the config")
-        self._drained = {}
 
     def _fn(self, name):
         return getattr(self._lib, "ro_" + name)
@@ -89,7 +89,6 @@ class OracleEngine(EngineBase):
 
     def reset(self):
         self._lib.ro_reset(self._h)
-        self._drained = {}
 
     def sync(self):
         pass
@@ -133,12 +132,14 @@ class OracleEngine(EngineBase):
         return self._lib.ro_commit_rule(self._h, g, leader)
 
     def drain_applied(self, g, p, cap=None):
-        """ApplyMsgs since the last drain, rebuilt from the cursor and the log."""
-        applied = int(self.read("applied")[g, p])
-        cmds = self.read("logcmd")[g, p]
-        last = self._drained.get((g, p), 0)
-        if applied < last:
-            last = 0
-        out = [(i, int(cmds[i])) for i in range(last + 1, applied + 1)]
-        self._drained[(g, p)] = applied
+        """applyCh: the ApplyMsgs the slot emitted since the last drain, as emitted (needs apply_ring_cap > 0)."""
+        cap = cap or max(self.L, self.cfg.apply_ring_cap)
+        buf = (ApplyMsgC * cap)()
+        n = C.c_int64()
+        st = self._lib.ro_drain_applied(self._h, g, p, buf, cap, C.byref(n))
+        out = [(int(buf[i].command_index), int(buf[i].command)) for i in range(n.value)]
+        if st != 0:
+            err = RaftGpuError(st, "drain_applied")
+            err.partial = out
+            raise err
         return out

@@ -59,6 +59,8 @@ typedef struct {
   uint64_t applyHash;
   int32_t *logTerm;  uint64_t *logCmd;
   int32_t *snapTerm_; uint64_t *snapCmd_;
+  /* applyCh, raft.go:680-684: what the slot's peers sent, in order (a ring of cfg.apply_ring_cap messages) */
+  rg_apply_msg *applyRing; uint32_t applyHead, applyDrained;
 } peer_t;
 
 typedef struct {
@@ -486,6 +488,10 @@ static void apply_step(ro_engine *e, ctr_t *c, group_t *g, int p) {
     if (idx >= rf->logLen) g->flags |= RG_FLAG_REF_PANIC;
     if (idx >= e->L) idx = e->L - 1;
     uint64_t cmd = rf->logCmd[idx];
+    if (rf->applyRing) {           /* rf.applyCh <- ApplyMsg{true, logs[lastApplied].Command, lastApplied} */
+      rg_apply_msg *m = &rf->applyRing[rf->applyHead++ % (uint32_t)e->cfg.apply_ring_cap];
+      m->command_index = rf->applied; m->command = cmd;
+    }
     {  /* apply digest: two independent 32-bit sums of a hash of (index, command), so that entries can be folded in any order */
       uint64_t wd = sm64(cmd ^ ((uint64_t)(uint32_t)rf->applied << 40));
       uint32_t lo = (uint32_t)rf->applyHash + (uint32_t)wd, hi = (uint32_t)(rf->applyHash >> 32) + (uint32_t)(wd >> 32);
@@ -608,8 +614,9 @@ static void init_group(ro_engine *e, group_t *g, int64_t ggid) {
   for (int p = 0; p < e->P; p++) {
     peer_t *rf = &g->peer[p];
     int32_t *lt = rf->logTerm, *st = rf->snapTerm_; uint64_t *lc = rf->logCmd, *sc = rf->snapCmd_;
+    rg_apply_msg *ring = rf->applyRing;
     memset(rf, 0, sizeof *rf);
-    rf->logTerm = lt; rf->snapTerm_ = st; rf->logCmd = lc; rf->snapCmd_ = sc;
+    rf->logTerm = lt; rf->snapTerm_ = st; rf->logCmd = lc; rf->snapCmd_ = sc; rf->applyRing = ring;
     memset(lt, 0, sizeof(int32_t) * (size_t)e->L); memset(st, 0, sizeof(int32_t) * (size_t)e->L);
     memset(lc, 0, sizeof(uint64_t) * (size_t)e->L); memset(sc, 0, sizeof(uint64_t) * (size_t)e->L);
     rf->connected = 1; rf->side = 0;
@@ -623,6 +630,7 @@ static int valid_config(const rg_config *c) {
   if (c->n_groups < 1 || c->n_peers < 2 || c->n_peers > RG_MAX_PEERS || c->log_cap < 2) return 0;
   if (c->start_period < 0 || c->part_period < 0 || c->churn_period < 0) return 0;
   if (c->start_period > 0 && (c->start_max < 0 || c->start_max + 1 > c->log_cap)) return 0;
+  if (c->apply_ring_cap < 0) return 0;
   return 1;
 }
 
@@ -642,6 +650,7 @@ ro_engine *ro_create(const rg_config *cfg) {
       rf->snapTerm_ = (int32_t *)malloc(sizeof(int32_t) * (size_t)e->L);
       rf->logCmd = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)e->L);
       rf->snapCmd_ = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)e->L);
+      rf->applyRing = cfg->apply_ring_cap > 0 ? (rg_apply_msg *)calloc((size_t)cfg->apply_ring_cap, sizeof(rg_apply_msg)) : NULL;
     }
   }
   ro_reset(e);
@@ -661,6 +670,7 @@ void ro_destroy(ro_engine *e) {
     free(gr->applyRec);
     for (int p = 0; p < e->P; p++) {
       free(gr->peer[p].logTerm); free(gr->peer[p].snapTerm_); free(gr->peer[p].logCmd); free(gr->peer[p].snapCmd_);
+      free(gr->peer[p].applyRing);
     }
   }
   free(e->groups);
@@ -747,6 +757,24 @@ int ro_set_unreliable(ro_engine *e, int32_t a, int32_t b, int32_t d) {
   if (!e || a < 0 || b < 0 || d < 0 || a > 1000 || b > 1000 || d > 1000) return RG_ERR_ARG;
   e->cfg.req_drop_permille = a; e->cfg.reply_drop_permille = b; e->cfg.reply_delay_permille = d;
   return RG_OK;
+}
+
+/* the reader's end of applyCh: the messages sent since the last call, oldest first */
+int ro_drain_applied(ro_engine *e, int32_t g, int32_t p, rg_apply_msg *buf, int64_t cap, int64_t *n_out) {
+  CHECK_GP(e, g, p);
+  if (!n_out || cap < 0 || (cap > 0 && !buf)) return RG_ERR_ARG;
+  *n_out = 0;
+  peer_t *rf = &e->groups[g].peer[p];
+  if (!rf->applyRing) return RG_ERR_STATE;
+  const uint32_t rc = (uint32_t)e->cfg.apply_ring_cap;
+  int status = RG_OK;
+  if (rf->applyHead - rf->applyDrained > rc) { rf->applyDrained = rf->applyHead - rc; status = RG_ERR_OVERRUN; }
+  int64_t n = (int64_t)(rf->applyHead - rf->applyDrained);
+  if (n > cap) n = cap;
+  for (int64_t i = 0; i < n; i++) buf[i] = rf->applyRing[(rf->applyDrained + (uint32_t)i) % rc];
+  rf->applyDrained += (uint32_t)n;
+  *n_out = n;
+  return status;
 }
 
 int ro_rpc_request_vote(ro_engine *e, int32_t g, int32_t p, const rg_vote_args *a, rg_vote_reply *r) {

@@ -46,6 +46,8 @@ int ro_crash(ro_engine *e, int32_t g, int32_t p);
 int ro_restart(ro_engine *e, int32_t g, int32_t p);
 int ro_set_unreliable(ro_engine *e, int32_t req_drop, int32_t reply_drop, int32_t reply_delay);
 
+int ro_drain_applied(ro_engine *e, int32_t g, int32_t p, rg_apply_msg *buf, int64_t cap, int64_t *n_out);
+
 int ro_rpc_request_vote(ro_engine *e, int32_t g, int32_t p, const rg_vote_args *a, rg_vote_reply *r);
 int ro_rpc_append_entries(ro_engine *e, int32_t g, int32_t p, const rg_append_args *a,
                           const int32_t *entry_terms, const uint64_t *entry_cmds, rg_append_reply *r);

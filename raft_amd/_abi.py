@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("RAFTGPU_LIB") or os.path.join(HERE, "lib", "libraftgp
 # ---- constants mirrored from include/raftgpu.h ---------------------------
 TICK_MS = 10
 MAX_PEERS = 8
-OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_RANGE, ERR_STATE, ERR_SCRATCH = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_ARG, ERR_HIP, ERR_NOMEM, ERR_RANGE, ERR_STATE, ERR_SCRATCH, ERR_OVERRUN = 0, -1, -2, -3, -4, -5, -6, -7
 FOLLOWER, CANDIDATE, LEADER = 0, 1, 2
 
 FLAG_ELECTION_SAFETY = 0x01
@@ -61,7 +61,7 @@ class Config(C.Structure):
         ("part_period", C.c_int32), ("part_jitter", C.c_int32),
         ("churn_period", C.c_int32), ("churn_disconnect_permille", C.c_int32),
         ("churn_restart_permille", C.c_int32), ("churn_crash_permille", C.c_int32),
-        ("account_bytes", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("account_bytes", C.c_int32), ("apply_ring_cap", C.c_int32), ("reserved", C.c_int32 * 1),
     ]
 
     def as_dict(self):

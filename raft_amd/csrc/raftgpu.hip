@@ -83,7 +83,8 @@ struct rg_engine {
   long long launches;
   long long now;
   bool derivedDirty, syncDirty;
-  std::vector<int> drained;       // per (g,p): last index handed out by rg_drain_applied
+  std::vector<unsigned> drained;  // per (g,p): ApplyMsgs handed out by rg_drain_applied so far
+  rg_apply_msg *applyRing; unsigned *applyHead; int applyCap;
   std::mutex mu;
   // staging
   HostCmd *dCmd; size_t dCmdCap;
@@ -102,6 +103,7 @@ extern "C" const char *rg_strerror(int st) {
   case RG_ERR_NOMEM: return "out of memory";
   case RG_ERR_RANGE: return "group/peer/index out of range";
   case RG_ERR_STATE: return "illegal in this state";
+  case RG_ERR_OVERRUN: return "apply ring overrun: the oldest ApplyMsgs were overwritten before they were drained";
   case RG_ERR_SCRATCH: return "engine too large for the fixed device scratch of rg_step_noalloc";
   default: return "unknown status";
   }
@@ -123,6 +125,7 @@ static bool valid_config(const rg_config *c) {
   if (c->n_groups < 1 || c->n_peers < 2 || c->n_peers > RG_MAX_PEERS || c->log_cap < 2) return false;
   if (c->start_period < 0 || c->part_period < 0 || c->churn_period < 0) return false;
   if (c->start_period > 0 && (c->start_max < 0 || c->start_max + 1 > c->log_cap)) return false;
+  if (c->apply_ring_cap < 0) return false;
   if (c->req_drop_permille < 0 || c->req_drop_permille > 1000 || c->reply_drop_permille < 0 || c->reply_drop_permille > 1000 ||
       c->reply_delay_permille < 0 || c->reply_delay_permille > 1000) return false;
   return true;
@@ -178,7 +181,8 @@ static void fill_devcfg(rg_engine *e) {
     for (int gw = gwMax; gw >= gwMax - 1 && gw >= 1; gw--) {
       const long long gs = 4 * gw;                               // groups per set
       const bool whole = gs * e->PP * 4 % 128 == 0 && gs * e->PP * e->PP * 4 % 128 == 0 &&
-                         gs * e->L * e->rowBytes % 128 == 0 && gs * e->L * 8 % 128 == 0;
+                         gs * e->L * e->rowBytes % 128 == 0 && gs * e->L * 8 % 128 == 0 &&
+                         gs * e->P * (long long)sizeof(rg_apply_msg) * e->applyCap % 128 == 0;
       if (whole) { e->relayGw = gw; e->relaySets = (int)((e->G + gs - 1) / gs); break; }
     }
   }
@@ -196,6 +200,7 @@ static int init_state(rg_engine *e) {
   HIPCHK(hipMemsetAsync(S.applyRec, 0, (size_t)e->G * e->L * 8, st));
   HIPCHK(hipMemsetAsync(S.counters, 0, RG_CTR_SLOTS * 8, st));
   HIPCHK(hipMemsetAsync(S.flagSummary, 0, 8, st));
+  if (e->applyCap > 0) HIPCHK(hipMemsetAsync(e->applyHead, 0, (size_t)e->nLanes * sizeof(unsigned), st));
   HIPCHK(hipStreamSynchronize(st));
   e->now = 0; e->derivedDirty = false; e->syncDirty = false;
   std::fill(e->drained.begin(), e->drained.end(), 0);
@@ -269,6 +274,12 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (rc == RG_OK) rc = dalloc(e, &S.flagSummary, (size_t)2);
   if (rc != RG_OK) { free_engine(e); return rc; }
   e->drained.assign((size_t)e->G * e->P, 0);
+  e->applyCap = cfg->apply_ring_cap; e->applyRing = nullptr; e->applyHead = nullptr;
+  if (e->applyCap > 0) {
+    rc = dalloc(e, &e->applyRing, (size_t)e->G * e->P * e->applyCap);
+    if (rc == RG_OK) rc = dalloc(e, &e->applyHead, (size_t)e->nLanes);
+    if (rc != RG_OK) { free_engine(e); return rc; }
+  }
   fill_devcfg(e);
   if (e->relaySets > 0) {
     rc = dalloc(e, &e->relay, (size_t)e->relaySets + 1);
@@ -276,6 +287,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     if (rc != RG_OK) { free_engine(e); return rc; }
   }
   e->H.relay = e->relay; e->H.relayStage = e->relayStage;
+  e->H.applyRing = e->applyRing; e->H.applyHead = e->applyHead; e->H.applyCap = e->applyCap;
   e->H.logRows = S.logRows; e->H.snapRows = S.snapRows; e->H.nextIdx = S.nextIdx; e->H.matchIdx = S.matchIdx; e->H.applyRec = S.applyRec;
   if (dalloc(e, &e->dS, 1) != RG_OK || hipMemcpy(e->dS, &e->S, sizeof(DevPtrs), hipMemcpyHostToDevice) != hipSuccess) { free_engine(e); return RG_ERR_NOMEM; }
   rc = init_state(e);
@@ -369,7 +381,7 @@ static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage)
   if (getenv("RAFTGPU_TRACE_LAUNCH")) fprintf(stderr, "raftgpu: k_tick ticks=%d blocks=%d relay_sets=%d relay_chunk=%d groups_per_wave=%d\n", n_ticks, blocks, dc.relaySets, dc.relayChunk, dc.gwA);
   const DevPtrs *dS = e->dS;
 #define TICK_LAUNCH(PEERS) do { \
-    if (dc.acctBytes) hipLaunchKernelGGL((k_tick<PEERS, true>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
+    if (dc.acctBytes || H.applyCap > 0) hipLaunchKernelGGL((k_tick<PEERS, true>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
     else hipLaunchKernelGGL((k_tick<PEERS, false>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)
   switch (e->P) {
   case 2: TICK_LAUNCH(2); break;
@@ -563,9 +575,7 @@ extern "C" int rg_set_side(rg_engine *e, int32_t g, int32_t p, int32_t side) { L
 extern "C" int rg_crash(rg_engine *e, int32_t g, int32_t p) { LOCK(e); return run_one(e, OP_CRASH, g, p, 0, nullptr); }
 extern "C" int rg_restart(rg_engine *e, int32_t g, int32_t p) {
   LOCK(e);
-  int rc = run_one(e, OP_RESTART, g, p, 0, nullptr);
-  if (rc == RG_OK) e->drained[(size_t)g * e->P + p] = 0;     // the new instance replays from index 1 (raft.go:717)
-  return rc;
+  return run_one(e, OP_RESTART, g, p, 0, nullptr);   // the new instance replays from index 1 (raft.go:717) into the same apply ring
 }
 
 extern "C" int rg_set_unreliable(rg_engine *e, int32_t a, int32_t b, int32_t d) {
@@ -592,25 +602,32 @@ extern "C" int rg_drain_applied(rg_engine *e, int32_t g, int32_t p, rg_apply_msg
   LOCK(e);
   if (!n_out || cap < 0 || (cap > 0 && !buf)) return RG_ERR_ARG;
   if (g < 0 || g >= e->G || p < 0 || p >= e->P) return RG_ERR_RANGE;
-  int applied = 0;
-  int rc = d2h(e, &applied, e->S.applied + (size_t)g * e->PP + p, 4);
+  *n_out = 0;
+  if (e->applyCap <= 0) return RG_ERR_STATE;          // the engine was created without an apply ring
+  unsigned head = 0;
+  int rc = d2h(e, &head, e->applyHead + (size_t)g * e->PP + p, 4);
   if (rc != RG_OK) return rc;
-  int &cur = e->drained[(size_t)g * e->P + p];
-  if (applied < cur) cur = 0;
-  int64_t n = applied - cur;
-  if (n > cap) n = cap;
-  if (n > 0) {
-    std::vector<char> rows((size_t)n * e->rowBytes);
-    rc = d2h(e, rows.data(), e->S.logRows + ((size_t)g * e->L + cur + 1) * e->rowBytes, rows.size());
-    if (rc != RG_OK) return rc;
-    for (int64_t i = 0; i < n; i++) {
-      buf[i].command_index = cur + 1 + i;
-      memcpy(&buf[i].command, rows.data() + (size_t)i * e->rowBytes + e->cmdOff + 8 * (size_t)p, 8);
-    }
-    cur += (int)n;
+  unsigned &cur = e->drained[(size_t)g * e->P + p];
+  int status = RG_OK;
+  if (head - cur > (unsigned)e->applyCap) {           // the peer emitted more than the ring holds since the last drain
+    cur = head - (unsigned)e->applyCap;               // the oldest message still there
+    status = RG_ERR_OVERRUN;
   }
+  int64_t n = (int64_t)(head - cur);
+  if (n > cap) n = cap;
+  const rg_apply_msg *ring = e->applyRing + ((size_t)g * e->P + p) * (size_t)e->applyCap;
+  int64_t done = 0;
+  while (done < n) {                                  // at most two stretches: the ring wraps
+    const unsigned slot = (cur + (unsigned)done) % (unsigned)e->applyCap;
+    int64_t run = (int64_t)e->applyCap - slot;
+    if (run > n - done) run = n - done;
+    rc = d2h(e, buf + done, ring + slot, (size_t)run * sizeof(rg_apply_msg));
+    if (rc != RG_OK) return rc;
+    done += run;
+  }
+  cur += (unsigned)n;
   *n_out = n;
-  return RG_OK;
+  return status;
 }
 
 extern "C" int rg_snapshot_export(rg_engine *e, int32_t g, int32_t p, void *buf, int64_t cap, int64_t *size_out) {

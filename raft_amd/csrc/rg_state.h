@@ -163,6 +163,9 @@ struct HotPtrs {
   char *logRows, *snapRows; int *nextIdx, *matchIdx; u64 *applyRec;
   int *relay;                    // relay launches: [0] next item, [1 + set] chunks of the set that are done
   int *relayStage;               // relay launches: per set, 7 words per group (the 5 per-group words, rounds sent before and in the last span), padded to whole 128-B lines
+  rg_apply_msg *applyRing;       // [G * P][applyCap]: the ApplyMsgs each peer emitted, in order, slot = message number % applyCap
+  unsigned *applyHead;           // [Gpad * PP], indexed like the per-peer words: messages emitted so far
+  int applyCap;                  // 0: no ring (nobody reads applyCh from the host)
 };
 
 __device__ static inline void ctr_add(WaveCtr *w, int which, unsigned v) { atomicAdd(&w->c[which], v); }

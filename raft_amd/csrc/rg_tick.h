@@ -163,10 +163,10 @@ __device__ static inline int turn_start(u64 key, int tick, int P) {
 #define RG_TICK_WAVES 4   // waves per SIMD the register allocation must allow
 #endif
 // Ticks [t0, t0 + nticks) of one block's worth of groups (`set`: what blockIdx.x is in a plain launch), by the
-// whole block.  BYTES: wire-byte accounting compiled in (rg_config.account_bytes); the plain instantiation
-// carries none of it.  w: the calling wave's counters of the launch.  stIn / stOut: the set's group words as the
+// whole block.  EXT: the extended instantiation, with wire-byte accounting (rg_config.account_bytes) and the
+// apply ring (rg_config.apply_ring_cap) compiled in; the plain instantiation carries none of it.  w: the calling wave's counters of the launch.  stIn / stOut: the set's group words as the
 // previous span left them / for the next span, when spans of one launch run on different blocks (else null).
-template <int P, bool BYTES>
+template <int P, bool EXT>
 __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, const DevCfg &c, const int set, const int t0, const int nticks, WaveCtr *w,
                                           const int *stIn, int *stOut) {
   constexpr int PP = P <= 4 ? 4 : 8;        // stride of a group in the per-peer arrays and matrices in memory
@@ -225,7 +225,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 #define rec(i) recBlk[rOff + (unsigned)(i)]
   u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
-  __shared__ int coldLds[CD_N + 6 + (BYTES ? 2 : 0)][256];   // peer words, 5 group words, the checked-apply cursor, per-lane byte sums
+  __shared__ int coldLds[CD_N + 6 + (EXT ? 2 : 0)][256];   // peer words, 5 group words, the checked-apply cursor, per-lane byte sums
   __shared__ int churnNext[GPB];                              // per group: its next churn tick (written by all its lanes alike)
   // The last RING entries each peer wrote to its log, staged in LDS: a follower copies a leader's fresh entries,
   // and every peer applies its fresh entries, without a trip to HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
@@ -248,7 +248,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     const int sent = G.gsum(valid ? r.cd(CD_ROUNDSEQ) : 0);
     if (valid && peer == 0) stOut[5 * GPBPAD + gLoc] = sent;
   }
-  if constexpr (BYTES) { coldLds[CD_N + 6][threadIdx.x] = 0; coldLds[CD_N + 7][threadIdx.x] = 0; }
+  if constexpr (EXT) { coldLds[CD_N + 6][threadIdx.x] = 0; coldLds[CD_N + 7][threadIdx.x] = 0; }
 #define gPartNext coldLds[CD_N + 3][threadIdx.x]
 #define gRecMax coldLds[CD_N + 4][threadIdx.x]
   gPartNext = stIn ? stIn[2 * GPBPAD + gLoc] : Sp->partNext[gq]; gRecMax = stIn ? stIn[3 * GPBPAD + gLoc] : Sp->recMax[gq];
@@ -604,7 +604,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok), grantM = G.ballot(ok && d.grant);
           const unsigned failM = G.ballot(called && (outW & NET_FAIL_FAST));
-          if constexpr (BYTES) atomicAdd((unsigned *)&coldLds[CD_N + 6][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
+          if constexpr (EXT) atomicAdd((unsigned *)&coldLds[CD_N + 6][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
           const int busy = round_busy<P>(calledM, okM, failM, delays);
           bool won = false;
           if (wantRV) {
@@ -860,7 +860,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
           const unsigned failM = G.ballot(called && (outW & NET_FAIL_FAST));
-          if constexpr (BYTES) {   // wire bytes: summed per target lane in LDS words of its own, added to the counters when the launch ends
+          if constexpr (EXT) {   // wire bytes: summed per target lane in LDS words of its own, added to the counters when the launch ends
             atomicAdd((unsigned *)&coldLds[CD_N + 6][tid], called ? (unsigned)RG_APPEND_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_APPEND_REPLY_BYTES : 0u) : 0u);
             atomicAdd((unsigned *)&coldLds[CD_N + 7][tid], (called && k > 0) ? (unsigned)k : 0u);
           }
@@ -970,6 +970,35 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           gRecMax = newMax;
           storesPending = true;
         }
+        if constexpr (EXT) {
+          // applyCh (raft.go:680-684): every ApplyMsg goes into the peer's ring at apply time, with the command the log
+          // holds then; head counts the messages the slot's peers have emitted since the engine was created or reset
+          // (a restarted peer replays from index 1 into the same ring).  By the whole wave, one entry per lane.
+          u64 am = H.applyCap > 0 ? __builtin_amdgcn_ballot_w64(act) : 0ull;
+          if (am) {
+            SYNC_STORES();
+            const unsigned dense = (unsigned)(g * P + peer);       // the ring's index of this peer
+            unsigned head = 0;
+            if (act) { head = H.applyHead[gl]; WAIT_LOADS(); }
+            const int nOwn = act ? r.commit - applied : 0;
+            do {
+              const int src = (int)__builtin_ctzll(am);
+              am &= am - 1;
+              const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), col = (unsigned)__builtin_amdgcn_readlane(peer, src);
+              const int lo = __builtin_amdgcn_readlane(applied, src), n = __builtin_amdgcn_readlane(nOwn, src);
+              const unsigned hd = (unsigned)__builtin_amdgcn_readlane((int)head, src), dn = (unsigned)__builtin_amdgcn_readlane((int)dense, src);
+              rg_apply_msg *const ring = H.applyRing + (size_t)dn * (size_t)H.applyCap;
+              for (int j = G.lane; j < n; j += 64) {
+                const int i = lo + 1 + j, ic = i < L ? i : L - 1;
+                const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
+                rg_apply_msg m; m.command_index = i; m.command = cmd;
+                ring[(hd + (unsigned)j) % (unsigned)H.applyCap] = m;
+              }
+            } while (am);
+            if (act) H.applyHead[gl] = head + (unsigned)nOwn;
+            storesPending = true;
+          }
+        }
         if (act) {
           ctr_add(w, RG_C_ENTRIES_APPLIED, (unsigned)(r.commit - applied));
           r.cd(CD_APPLIED) = r.commit;
@@ -1007,7 +1036,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 #undef SYNC_STORES
 #undef RING_PUSH
   const int startSeqOut = gStartSeq, partEpochOut = gPartEpoch, partNextOut = gPartNext, recMaxOut = gRecMax;
-  if constexpr (BYTES) {
+  if constexpr (EXT) {
     if (coldLds[CD_N + 6][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 6][threadIdx.x]);
     if (coldLds[CD_N + 7][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 7][threadIdx.x]);
   }
@@ -1054,7 +1083,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 // of its own to write back is not known to be refetched for its other bytes: the per-group words travel through
 // a staging area with whole lines per set instead (the host lays out relay launches so that no other array has
 // a line with two sets in it).
-template <int P, bool BYTES>
+template <int P, bool EXT>
 __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
   __shared__ WaveCtr sctr[4];
   __shared__ int sItem;
@@ -1083,7 +1112,7 @@ __global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, 
     }
   }
   __syncthreads();
-  tick_span<P, BYTES>(Sp, H, c, set, t0, nticks, w, stIn, stOut);
+  tick_span<P, EXT>(Sp, H, c, set, t0, nticks, w, stIn, stOut);
   if (c.relaySets > 0) {
     __syncthreads();                                 // every wave's stores have reached the L2; thread 0's release writes it back
     if (threadIdx.x == 0) {

@@ -182,11 +182,18 @@ class Engine(EngineBase):
         return reqs["index"].copy(), reqs["term"].copy(), reqs["is_leader"].astype(bool)
 
     def drain_applied(self, g, p, cap=None):
-        cap = cap or self.L
+        """applyCh: the ApplyMsgs the slot emitted since the last drain, as emitted (needs apply_ring_cap > 0).
+        On an overrun of the ring raises RaftGpuError(ERR_OVERRUN) whose `.partial` holds what was still there."""
+        cap = cap or max(self.L, self.cfg.apply_ring_cap)
         buf = (ApplyMsgC * cap)()
         n = C.c_int64()
-        self._check(self._lib.rg_drain_applied(self._h, g, p, buf, cap, C.byref(n)), "drain_applied")
-        return [(int(buf[i].command_index), int(buf[i].command)) for i in range(n.value)]
+        st = self._lib.rg_drain_applied(self._h, g, p, buf, cap, C.byref(n))
+        out = [(int(buf[i].command_index), int(buf[i].command)) for i in range(n.value)]
+        if st != 0:
+            err = RaftGpuError(st, "drain_applied")
+            err.partial = out
+            raise err
+        return out
 
     def request_vote(self, g, p, term, candidate, last_log_index, last_log_term):
         """One RequestVote RPC (reference: src/raft/raft.go:200-232)."""

@@ -387,9 +387,74 @@ def rng_draw_points(mk):
     assert (e.read("timeout")[0, 0], e.read("rngctr")[0, 0]) == (1000, 1)
 
 
+def apply_stream_keeps_what_was_applied(mk):
+    """applyCh carries logs[lastApplied].Command as it is when the entry is applied (raft.go:677-685), and a
+    restarted peer replays from index 1 (lastApplied = 0 at Make, raft.go:717).  Same schedule as
+    applied_entry_overwritten, but peer 0 applies x2 = 222 at index 2 itself, crashes, and comes back after the
+    others replaced index 2 by 333: drained only at the very end, its stream is still (2, 222), then the replay
+    (1, 111), then (2, 333) -- not what its log holds at drain time."""
+    e = mk(n_groups=1, n_peers=5, log_cap=16, seed=1, apply_ring_cap=16)
+    e.step(30)
+    assert e.start(0, 0, 111)[0] == 1
+    e.step(20)
+    assert [e.drain_applied(0, p) for p in range(5)] == [[(1, 111)]] * 5
+    for p in (0, 1, 2):
+        _set_log(e, 0, p, [0, 1, 1], cmds=[0, 111, 222])
+    e.set_connected(0, 0, False)
+    _put(e, "commit", 0, 0, 2)                             # the leader counted x2 on B, C (raft.go:409-411) ...
+    e.step(1)
+    assert e.read("applied")[0, 0] == 2                    # ... and applied it
+    e.crash(0, 0)
+    _put(e, "timer", 0, 3, -5000)                          # D is the first to time out
+    for _ in range(400):
+        e.step(1)
+        if e.get_state(0, 3)[1]:
+            break
+    assert e.get_state(0, 3) == (2, True)
+    assert e.start(0, 3, 333) == (2, 2, True)
+    e.step(40)
+    e.restart(0, 0)                                        # from its persisted [init, 111] (raft.go:120: commitIndex was 1 at its last persist)
+    e.set_connected(0, 0, True)
+    e.step(60)
+    assert e.read("logcmd")[0, :, 2].tolist() == [333] * 5
+    assert e.drain_applied(0, 0) == [(2, 222), (1, 111), (2, 333)]
+    assert [e.drain_applied(0, p) for p in (1, 2, 3, 4)] == [[(2, 333)]] * 4
+    assert e.drain_applied(0, 0) == []
+    assert e.safety_flags()[0] & _abi.FLAG_STATE_MACHINE
+
+
+def apply_ring_overrun_is_reported(mk):
+    """A reader that lets more than apply_ring_cap messages pile up is told so once (RG_ERR_OVERRUN) and gets
+    the newest apply_ring_cap messages; without a ring there is no applyCh to read (RG_ERR_STATE)."""
+    from raft_amd.engine import RaftGpuError
+    e = mk(n_groups=1, n_peers=3, log_cap=32, seed=1, apply_ring_cap=4)
+    e.step(30)
+    for i in range(10):
+        assert e.start(0, 0, 100 + i)[0] == i + 1
+    e.step(30)
+    assert e.read("applied")[0].tolist() == [10, 10, 10]
+    try:
+        e.drain_applied(0, 1)
+        raise AssertionError("overrun not reported")
+    except RaftGpuError as err:
+        assert err.status == _abi.ERR_OVERRUN
+        assert err.partial == [(7, 106), (8, 107), (9, 108), (10, 109)]
+    assert e.drain_applied(0, 1) == []
+    assert e.start(0, 0, 555)[0] == 11
+    e.step(30)
+    assert e.drain_applied(0, 1) == [(11, 555)]
+    e = mk(n_groups=1, n_peers=3, log_cap=32, seed=1)
+    try:
+        e.drain_applied(0, 0)
+        raise AssertionError("drain without a ring")
+    except RaftGpuError as err:
+        assert err.status == _abi.ERR_STATE
+
+
 CASES = {f.__name__: f for f in (
     boot_and_three_starts, conflict_reply, append_truncates_unconditionally, leader_backoff, commit_rule,
     vote_compares_commit_index, restore_repersists_one_entry, start_on_isolated_leader, stop_rule,
     applied_entry_overwritten, same_term_vote_request_demotes_leader, candidate_steps_down_without_adopting_term,
     leader_adopts_term_keeps_vote, votes_are_counted_per_reply, late_vote_replies_are_lost,
-    failed_candidate_retries_same_term, rng_draw_points)}
+    failed_candidate_retries_same_term, rng_draw_points, apply_stream_keeps_what_was_applied,
+    apply_ring_overrun_is_reported)}

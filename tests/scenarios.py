@@ -9,7 +9,7 @@ from raft_amd.harness import Config, TestFailure, ELECTION_TIMEOUT_TICKS as ET
 
 
 def _cfg(make_engine, servers, unreliable=False, log_cap=512, seed=1):
-    eng = make_engine(n_groups=1, n_peers=servers, log_cap=log_cap, seed=seed, account_bytes=1)
+    eng = make_engine(n_groups=1, n_peers=servers, log_cap=log_cap, seed=seed, account_bytes=1, apply_ring_cap=log_cap)
     return Config(eng, 0, unreliable)
 
 

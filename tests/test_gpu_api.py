@@ -97,7 +97,7 @@ def test_request_vote_handler_random_states(peers, seed):
 
 
 def test_start_batch_drain_and_snapshots():
-    kw = dict(n_groups=40, n_peers=5, log_cap=64, seed=8)
+    kw = dict(n_groups=40, n_peers=5, log_cap=64, seed=8, apply_ring_cap=64)
     o, e = _pair(**kw)
     o.step(40)
     e.step(40)

@@ -43,3 +43,33 @@ def test_relay_matches_oracle(monkeypatch, capfd, kw, groups, slot_waves, chunks
     assert e.counters()["entries_committed"] > 0
     trace = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("raftgpu: k_tick")]
     assert len(trace) == len(launches) and all("relay_sets=%d " % sets in ln for ln in trace), trace
+
+
+@pytest.mark.parametrize("kw,groups,slot_waves,chunks,ticks", [
+    (CHURN, 150, 4, 4, 1200),       # relay launch: a peer's ring is written by several blocks of one launch
+    (CHURN, 40, 0, 0, 1500),        # plain launch
+    (LOSSY, 200, 8, 3, 900),
+])
+def test_apply_streams_match_oracle(monkeypatch, kw, groups, slot_waves, chunks, ticks):
+    """applyCh of every peer after ONE long launch with crashes, restarts (replays from index 1) and truncations:
+    the engine's rings hold the oracle's streams message for message."""
+    from oracle.binding import OracleEngine
+    from raft_amd import Engine
+    if slot_waves:
+        monkeypatch.setenv("RAFTGPU_SLOT_WAVES", str(slot_waves))
+        monkeypatch.setenv("RAFTGPU_RELAY_CHUNKS", str(chunks))
+    cfg = dict(kw, n_groups=groups, apply_ring_cap=2048)
+    o, e = OracleEngine(_abi.make_config(**cfg)), Engine(_abi.make_config(**cfg))
+    replays = 0
+    for n in (ticks, 37):
+        o.step_mt(n, 8)
+        e.step(n)
+        assert not diff_states(o, e)
+        for g in range(groups):
+            for p in range(cfg["n_peers"]):
+                mo = o.drain_applied(g, p)
+                assert mo == e.drain_applied(g, p), (g, p)
+                idx = [i for i, _ in mo]
+                replays += sum(1 for a, b in zip(idx, idx[1:]) if b == 1)
+    if "churn_period" in kw:
+        assert replays > 0

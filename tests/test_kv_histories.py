@@ -18,7 +18,7 @@ SEEDS = {"partitions": 5}    # a seed under which one of the 8 groups loses a co
 
 
 def _histories(make_engine, net, groups=8, ticks=1500):
-    e = make_engine(_abi.make_config(n_groups=groups, n_peers=5, log_cap=2048, seed=SEEDS.get(net, 3), **NETS[net]))
+    e = make_engine(_abi.make_config(n_groups=groups, n_peers=5, log_cap=2048, apply_ring_cap=2048, seed=SEEDS.get(net, 3), **NETS[net]))
     kc = KvCluster(e, range(groups), n_clients=5, seed=1)
     hs = kc.run(ticks)
     flags = e.safety_check()

@@ -56,3 +56,28 @@ def test_results_do_not_depend_on_sharding(mk):
     assert np.array_equal(whole.state_hash()[32:], shard.state_hash())
     for f in ("term", "commit", "loglen", "applyhash"):
         assert np.array_equal(whole.read(f)[32:], shard.read(f))
+
+
+CHURN = dict(n_groups=12, n_peers=5, log_cap=256, seed=5, req_drop_permille=50, reply_drop_permille=50, start_period=3,
+             start_max=200, start_mode=_abi.START_ALL, churn_period=70, churn_disconnect_permille=200,
+             churn_restart_permille=500, churn_crash_permille=200, apply_ring_cap=4096)
+
+
+def test_apply_stream_of_a_churn_launch_holds_the_replays(mk):
+    """Peers restarted by the device-side churn inside ONE launch replay their restored log from index 1
+    (raft.go:717, 677-685): the drained stream shows it, and every message is the tester's record of its index
+    unless the group was flagged."""
+    e = mk(**CHURN)
+    e.step(3000)
+    replays = 0
+    rec, flags = e.read("applyrec"), e.read("gflags")
+    for g in range(12):
+        for p in range(5):
+            msgs = e.drain_applied(g, p)
+            idx = [i for i, _ in msgs]
+            replays += sum(1 for a, b in zip(idx, idx[1:]) if b == 1)
+            assert all(b == a + 1 or b == 1 for a, b in zip(idx, idx[1:]))     # in order within an incarnation
+            if flags[g] == 0:
+                assert all(rec[g, i] == c for i, c in msgs)
+    assert replays > 5
+    assert sum(e.counters()[k] for k in ("entries_applied",)) > 0
