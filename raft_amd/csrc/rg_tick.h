@@ -1036,7 +1036,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 #undef SYNC_STORES
 #undef RING_PUSH
   const int startSeqOut = gStartSeq, partEpochOut = gPartEpoch, partNextOut = gPartNext, recMaxOut = gRecMax;
-  if constexpr (EXT) {
+  if (EXT && c.acctBytes) {
     if (coldLds[CD_N + 6][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 6][threadIdx.x]);
     if (coldLds[CD_N + 7][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 7][threadIdx.x]);
   }

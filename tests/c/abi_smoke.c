@@ -11,7 +11,7 @@ int main(void) {
   if (rg_device_count() < 1) { printf("FAIL no gfx950 device\n"); return 2; }
   rg_config cfg;
   memset(&cfg, 0, sizeof cfg);
-  cfg.n_groups = 64; cfg.n_peers = 3; cfg.log_cap = 64; cfg.seed = 1;
+  cfg.n_groups = 64; cfg.n_peers = 3; cfg.log_cap = 64; cfg.seed = 1; cfg.apply_ring_cap = 64;   /* applyCh is read below */
   rg_engine *e = NULL;
   CHECK(rg_create(&cfg, &e));
   CHECK(rg_step(e, 100));                                  /* one second: an election */
