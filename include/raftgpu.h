@@ -115,7 +115,10 @@ enum {
   RG_F_LOGTERM = 48, RG_F_SNAPLOGTERM,  /* int32 [G][P][L]                   */
   RG_F_LOGCMD = 56, RG_F_SNAPLOGCMD,    /* uint64 [G][P][L]                  */
   RG_F_STARTSEQ = 64, RG_F_PARTNEXT, RG_F_PARTEPOCH, RG_F_RECMAX, RG_F_GFLAGS, /* int32 [G] */
-  RG_F_APPLYREC = 72                 /* uint64 [G][L]                        */
+  RG_F_APPLYREC = 72,                /* uint64 [G][L]                        */
+  /* read-only, int32 [G][P]: the engine's cached copies of log words (term of the last entry, first index from
+   * which every entry carries currentTerm, term of the entry at commitIndex), for consistency checks */
+  RG_F_CACHE_LASTTERM = 80, RG_F_CACHE_FIRSTOWN, RG_F_CACHE_COMMITTERM
 };
 
 /* ---- Start injection modes (device-side client workload) ---------------- */

@@ -242,6 +242,8 @@ enum { NET_LOST = 0, NET_REPLY_LOST = 1, NET_OK = 2 };
  * or false, or 25 ms, whichever comes first.  A request or reply the net drops makes Call return false right
  * after the net's short delay (labrpc.go:226-229, 273-275); a Call to an unreachable peer returns false after
  * 0..6999 ms (labrpc.go:290-305: the whole 25 ms here), a long-reordered reply comes after 200 ms or more. */
+static inline int32_t permille_of(uint32_t field16) { return (int32_t)((field16 * 1000u) >> 16); }
+
 static int net_outcome(const ro_engine *e, const group_t *g, int s, int j, uint32_t seq, int32_t *cost, int *wire) {
   const peer_t *a = &g->peer[s], *b = &g->peer[j];
   *cost = RG_RPC_WAIT_MS;
@@ -249,16 +251,15 @@ static int net_outcome(const ro_engine *e, const group_t *g, int s, int j, uint3
   if (!(a->connected && b->connected && a->side == b->side) || b->dead) return NET_LOST;
   const rg_config *cf = &e->cfg;
   if (cf->req_drop_permille == 0 && cf->reply_drop_permille == 0 && cf->reply_delay_permille == 0) { *cost = 0; *wire = 1; return NET_OK; }
+  /* one hash per Call: 16 bits each for the two drop draws and the reordering draw, 8 bits for the delay */
   uint64_t h = stream_hash(g->key, STREAM_NET, ((uint32_t)s << 8) | (uint32_t)j, seq);
-  /* the delays of one round come from one hash, 8 bits per target */
-  uint64_t delays = stream_hash(g->key, STREAM_NET, 0xFFFF0000u | (uint32_t)s, seq);
-  int32_t d = (int32_t)((((delays >> (8 * j)) & 0xFF) * RG_NET_DELAY_SPAN_MS) >> 8);         /* :222, 0..26 */
+  int32_t d = (int32_t)((((h >> 48) & 0xFF) * RG_NET_DELAY_SPAN_MS) >> 8);                   /* :222, 0..26 */
   int32_t back = d < RG_RPC_WAIT_MS ? d : RG_RPC_WAIT_MS;           /* Call returns after d ms; the select gives up at 25 */
-  if ((int32_t)((h & 0xFFFFF) % 1000) < cf->req_drop_permille) { *cost = back; return NET_LOST; }   /* :226-229 */
-  *wire = !((int32_t)(((h >> 20) & 0xFFFFF) % 1000) < cf->reply_drop_permille);              /* :273 */
+  if (permille_of((uint32_t)(h & 0xFFFF)) < cf->req_drop_permille) { *cost = back; return NET_LOST; }   /* :226-229 */
+  *wire = !(permille_of((uint32_t)((h >> 16) & 0xFFFF)) < cf->reply_drop_permille);           /* :273 */
   if (!*wire) { *cost = back; return NET_REPLY_LOST; }               /* :273-275 */
   if (d >= RG_RPC_WAIT_MS) return NET_REPLY_LOST;                    /* handler runs, the sender has given up */
-  if ((int32_t)(((h >> 40) & 0xFFFFF) % 1000) < cf->reply_delay_permille) return NET_REPLY_LOST;  /* :276-285 */
+  if (permille_of((uint32_t)((h >> 32) & 0xFFFF)) < cf->reply_delay_permille) return NET_REPLY_LOST;  /* :276-285 */
   *cost = d;
   return NET_OK;
 }
@@ -524,10 +525,9 @@ static void control_step(ro_engine *e, ctr_t *c, group_t *g, int32_t now /* tick
   const int P = e->P;
   /* rolling partitions, kvraft/test_test.go:124-143 + kvraft/config.go:174-186 */
   if (cf->part_period > 0 && now == g->partNext) {
-    uint32_t ep = (uint32_t)g->partEpoch;
-    for (int p = 0; p < P; p++) g->peer[p].side = (int32_t)(stream_hash(g->key, STREAM_PART, ep, (uint32_t)p + 1) & 1);
-    uint64_t h = stream_hash(g->key, STREAM_PART, ep, 0);
-    g->partNext = now + cf->part_period + (cf->part_jitter > 0 ? (int32_t)(h % (uint64_t)cf->part_jitter) : 0);
+    uint64_t h = stream_hash(g->key, STREAM_PART, (uint32_t)g->partEpoch, 0);
+    for (int p = 0; p < P; p++) g->peer[p].side = (int32_t)((h >> p) & 1);
+    g->partNext = now + cf->part_period + (int32_t)(((h >> 32) * (uint64_t)(uint32_t)cf->part_jitter) >> 32);
     g->partEpoch++;
   }
   /* churn, test_test.go:893-919 */

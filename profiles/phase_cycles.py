@@ -4,7 +4,7 @@ usage: RAFTGPU_LIB=raft_amd/lib/libraftgpu_stamps.so python profiles/phase_cycle
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raft_amd import Engine, _abi
-G, T = int(os.environ.get("PG", 65536)), 4000
+G, T = int(os.environ.get("PG", 65536)), int(os.environ.get("PT", 4000))
 mode = sys.argv[1] if len(sys.argv) > 1 else "bench"
 kw = dict(n_groups=G, n_peers=5, log_cap=1024, seed=2)
 if mode == "bench":
@@ -24,9 +24,10 @@ def tick_waves(G, slots=4096, gw_max=12):
 
 
 wt = tick_waves(G) * T
-names = ["control", "classify", "(rest of actors)", "apply", "leader check", "pend header+election", "RV section", "monitor eval", "AE section"]
+names = ["client Starts", "classify", "(rest of actors)", "apply", "leader check", "pend header+election", "RV section", "monitor eval", "AE section",
+         "key + catch-up", "partitions, churn", "next event"]
 cnt = {"pend header+election": 0, "RV section": 1, "monitor eval": 2, "AE section": 3, "apply": 4}
-tot = sum(buf[40:49])
+tot = sum(buf[40:52])
 for i, n in enumerate(names):
     extra = ""
     if n in cnt and buf[_abi.N_COUNTERS + cnt[n]]:

@@ -352,10 +352,10 @@ static int run_derive(rg_engine *e) {
 // Ticks per chunk of a relay launch: chunks of at least RG_RELAY_MIN_TICKS, at most RG_RELAY_MAX_CHUNKS of them
 // (a chunk boundary costs a store and a load of the state, a cold start of the LDS rings and an L2 write-back;
 // measured on 65,536 five-peer groups x 20,000 ticks: 67.2 ms plain, 53.6 / 53.4 / 53.5 ms with 6 / 8 / 10 chunks,
-// 59.7 ms with 24; on 131,072 three-peer groups x 4,000 ticks at 1 % loss: 9.1 ms plain, 8.4 / 8.2 / 8.1 ms
+// 59.7 ms with 24 (a later, faster kernel: 48.3 / 48.0 / 47.8 / 47.7 / 47.8 ms with 6 / 8 / 10 / 12 / 16); on 131,072 three-peer groups x 4,000 ticks at 1 % loss: 9.1 ms plain, 8.4 / 8.2 / 8.1 ms
 // with 2 / 4 / 6 chunks).  0: plain launch.
 #define RG_RELAY_MIN_TICKS 1000
-#define RG_RELAY_MAX_CHUNKS 8
+#define RG_RELAY_MAX_CHUNKS 12
 static int relay_chunk_ticks(const rg_engine *e, int n_ticks) {
   if (e->relaySets == 0) return 0;
   int k = n_ticks / RG_RELAY_MIN_TICKS;
@@ -803,6 +803,7 @@ extern "C" int rg_rpc_append_entries(rg_engine *e, int64_t n, const int32_t *gro
   return RG_OK;
 }
 
+static int run_derive_if_dirty(rg_engine *e);
 // ---- bulk state access -----------------------------------------------------------
 static int64_t field_bytes(const rg_engine *e, int field) {
   int64_t G = e->G, P = e->P, L = e->L;
@@ -856,6 +857,18 @@ static int *group_word(rg_engine *e, int field) {
 
 static int rw_state(rg_engine *e, int field, void *buf, int64_t bytes, bool wr) {
   if (!buf) return RG_ERR_ARG;
+  if (field >= RG_F_CACHE_LASTTERM && field <= RG_F_CACHE_COMMITTERM) {
+    if (wr || bytes != (int64_t)e->G * e->P * 4) return RG_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int rcd = run_derive_if_dirty(e);
+    if (rcd != RG_OK) return rcd;
+    const int *dev = field == RG_F_CACHE_LASTTERM ? e->S.lastTerm : field == RG_F_CACHE_FIRSTOWN ? e->S.firstOwn : e->S.commitTerm;
+    std::vector<int> tmp((size_t)e->nLanes);
+    int rcc = d2h(e, tmp.data(), dev, tmp.size() * 4);
+    if (rcc != RG_OK) return rcc;
+    for (int g = 0; g < e->G; g++) for (int p = 0; p < e->P; p++) ((int32_t *)buf)[(size_t)g * e->P + p] = tmp[(size_t)g * e->PP + p];
+    return RG_OK;
+  }
   const int64_t need = field_bytes(e, field);
   if (need < 0 || bytes != need) return RG_ERR_ARG;
   const int G = e->G, P = e->P, L = e->L, PP = e->PP;
@@ -962,6 +975,7 @@ static int rw_state(rg_engine *e, int field, void *buf, int64_t bytes, bool wr) 
   return RG_ERR_ARG;
 }
 
+static int run_derive_if_dirty(rg_engine *e) { return run_derive(e); }
 extern "C" int rg_read_state(rg_engine *e, int32_t field, void *dst, int64_t bytes) { LOCK(e); return rw_state(e, field, dst, bytes, false); }
 extern "C" int rg_write_state(rg_engine *e, int32_t field, const void *src, int64_t bytes) { LOCK(e); return rw_state(e, field, (void *)src, bytes, true); }
 

@@ -95,7 +95,10 @@ struct WaveCtr { unsigned c[RG_WAVE_CTR_SLOTS]; };
 #define SECTION_COUNT(w, i) do { } while (0)
 #define SECTION_COUNT_LANE(w, i) do { } while (0)
 #endif
-#ifdef RG_STAMPS   // diagnostic builds only: shader cycles per phase of a tick, summed per wave into slots 40..
+#ifdef RG_MARKS    // diagnostic builds only: comment lines in the assembly at the phase boundaries, for static instruction counts
+#define STAMP(k) asm volatile("; MARK " #k)
+#define STAMP_INIT asm volatile("; MARK begin")
+#elif defined(RG_STAMPS)   // diagnostic builds only: shader cycles per phase of a tick, summed per wave into slots 40..
 #define STAMP(k) do { unsigned long long _n = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&w->c[40 + (k)], (unsigned)(_n - _stamp)); _stamp = _n; } while (0)
 #define STAMP_INIT unsigned long long _stamp = __builtin_readcyclecounter()
 #else

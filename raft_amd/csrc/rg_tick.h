@@ -95,54 +95,30 @@ struct GrpN {
 };
 
 __device__ static inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
-// The unreliable net's delays of one round, 8 bits per target (labrpc.go:222): one hash per round, so the
-// sender can add up its waits without asking the targets.
-__device__ static inline u64 round_delays(const DevCfg &c, u64 key, int s, unsigned seq) {
-  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) return 0;
-  return stream_hash(key, STREAM_NET, 0xFFFF0000u | (unsigned)s, seq);
-}
-__device__ static inline int delay_of(u64 delays, int j) { return (int)((((unsigned)(delays >> (8 * j)) & 0xFFu) * (unsigned)RG_NET_DELAY_SPAN_MS) >> 8); }
 // network outcome of one Call, labrpc.go:216-307: 0 lost, 1 handler ran / reply lost or late, 2 round trip;
-// bit 2 (NET_WIRE): the net carried the reply, in time or not, and counted its bytes (labrpc.go:286-290);
-// bit 3 (NET_FAIL_FAST): the net dropped the request or the reply, so Call returned false right after the
-// net's short delay (labrpc.go:226-229, 273-275) and the sender did not sit out its whole 25 ms wait
+// bit 2 (NET_WIRE): the net carried the reply, in time or not, and counted its bytes (labrpc.go:286-290).
+// cost: how long the sender's select (raft.go:469-474, 605-609) waits for this Call: until Call returns -- with a
+// reply, or false right after the net's short delay when the net drops the request or the reply (labrpc.go:226-229,
+// 273-275) -- or 25 ms, whichever is first.  One hash per Call holds its three draws and its delay, so every target
+// works out its own share of the round's duration and the sender adds them up.
 #define NET_WIRE 4
-#define NET_FAIL_FAST 8
-__device__ static inline int net_outcome(const DevCfg &c, u64 key, bool reachable, int s, int j, unsigned seq, u64 delays) {
+__device__ static inline int permille_of(unsigned field16) { return (int)((field16 * 1000u) >> 16); }
+__device__ static inline int net_outcome(const DevCfg &c, u64 key, bool reachable, int s, int j, unsigned seq, int &cost) {
+  cost = RG_RPC_WAIT_MS;
   if (!reachable) return 0;
-  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) return 2 | NET_WIRE;
-  u64 h = stream_hash(key, STREAM_NET, ((unsigned)s << 8) | (unsigned)j, seq);
-  if ((int)((unsigned)(h & 0xFFFFF) % 1000u) < c.reqDrop) return 0 | NET_FAIL_FAST;
-  if ((int)((unsigned)((h >> 20) & 0xFFFFF) % 1000u) < c.replyDrop) return 1 | NET_FAIL_FAST;
-  if (delay_of(delays, j) >= RG_RPC_WAIT_MS) return 1 | NET_WIRE;   // the handler runs, the sender has given up
-  if ((int)((unsigned)((h >> 40) & 0xFFFFF) % 1000u) < c.replyDelay) return 1 | NET_WIRE;
+  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) { cost = 0; return 2 | NET_WIRE; }
+  const u64 h = stream_hash(key, STREAM_NET, ((unsigned)s << 8) | (unsigned)j, seq);
+  const unsigned lo = (unsigned)h, hi = (unsigned)(h >> 32);
+  const int d = (int)((((hi >> 16) & 0xFFu) * (unsigned)RG_NET_DELAY_SPAN_MS) >> 8);          // labrpc.go:222, 0..26
+  const int back = d < RG_RPC_WAIT_MS ? d : RG_RPC_WAIT_MS;
+  if (permille_of(lo & 0xFFFFu) < c.reqDrop) { cost = back; return 0; }
+  if (permille_of(lo >> 16) < c.replyDrop) { cost = back; return 1; }
+  if (d >= RG_RPC_WAIT_MS) return 1 | NET_WIRE;   // the handler runs, the sender has given up
+  if (permille_of(hi & 0xFFFFu) < c.replyDelay) return 1 | NET_WIRE;
+  cost = d;
   return 2 | NET_WIRE;
 }
-// How long a round holds its sender (raft.go:469-474, 605-609 wait for Call's result or 25 ms, whichever comes
-// first): a Call that came back, with a reply (okM) or as a failure the net reported early (failM), costs the
-// net's delay, at most the 25 ms; every other Call the whole 25 ms.
-template <int P>
-__device__ static inline int round_busy(unsigned calledM, unsigned okM, unsigned failM, u64 delays) {
-  int busy = 0;
-  const unsigned backM = okM | failM;
-#pragma unroll
-  for (int j = 0; j < P; j++)
-    if ((calledM >> j) & 1u) {
-      const int d = delay_of(delays, j);
-      busy += (((backM >> j) & 1u) && d < RG_RPC_WAIT_MS) ? d : RG_RPC_WAIT_MS;
-    }
-  return busy;
-}
 
-// h % m without a 64-bit division when m fits 16 bits: 16 bits of h at a time, the running remainder stays below m
-__device__ static inline unsigned mod_u64(u64 h, unsigned m) {
-  if (m >= 0x10000u) return (unsigned)(h % (u64)m);
-  const unsigned hi = (unsigned)(h >> 32), lo = (unsigned)h;
-  unsigned r = hi % m;
-  r = ((r << 16) | (lo >> 16)) % m;
-  r = ((r << 16) | (lo & 0xFFFFu)) % m;
-  return r;
-}
 // scheduler slack of the election loop's 50 ms sleep: 0..3 ms, seeded
 __device__ static inline int sleep_slack(u64 key, int p, int now) {
   unsigned h = (unsigned)key ^ ((unsigned)p * 0x9E3779B1u) ^ ((unsigned)now * 0x85EBCA6Bu);
@@ -225,7 +201,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 #define rec(i) recBlk[rOff + (unsigned)(i)]
   u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
 
-  __shared__ int coldLds[CD_N + 6 + (EXT ? 2 : 0)][256];   // peer words, 5 group words, the checked-apply cursor, per-lane byte sums
+  __shared__ int coldLds[CD_N + 9 + (EXT ? 2 : 0)][256];   // peer words, 5 group words, the checked-apply cursor, the lane's cache of one leader's nextIndex / matchIndex pair, per-lane byte sums
   __shared__ int churnNext[GPB];                              // per group: its next churn tick (written by all its lanes alike)
   // The last RING entries each peer wrote to its log, staged in LDS: a follower copies a leader's fresh entries,
   // and every peer applies its fresh entries, without a trip to HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
@@ -248,7 +224,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     const int sent = G.gsum(valid ? r.cd(CD_ROUNDSEQ) : 0);
     if (valid && peer == 0) stOut[5 * GPBPAD + gLoc] = sent;
   }
-  if constexpr (EXT) { coldLds[CD_N + 6][threadIdx.x] = 0; coldLds[CD_N + 7][threadIdx.x] = 0; }
+  if constexpr (EXT) { coldLds[CD_N + 9][threadIdx.x] = 0; coldLds[CD_N + 10][threadIdx.x] = 0; }
 #define gPartNext coldLds[CD_N + 3][threadIdx.x]
 #define gRecMax coldLds[CD_N + 4][threadIdx.x]
   gPartNext = stIn ? stIn[2 * GPBPAD + gLoc] : Sp->partNext[gq]; gRecMax = stIn ? stIn[3 * GPBPAD + gLoc] : Sp->recMax[gq];
@@ -256,7 +232,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   // next ticks of the periodic control events (kept as counters: no division in the loop)
   // Within a launch each lane caches the nextIndex / matchIndex words ONE leader (cOwner) keeps for it; memory is
   // written through, so the matrices in HBM stay complete for other owners, dumps and digests.
-  int cOwner = -1, cNext = 0, cMatch = 0;
+#define cOwner coldLds[CD_N + 6][threadIdx.x]
+#define cNext coldLds[CD_N + 7][threadIdx.x]
+#define cMatch coldLds[CD_N + 8][threadIdx.x]
+  cOwner = -1; cNext = 0; cMatch = 0;
   // stores to words another lane may read later are drained (vmcnt) only right before such a read
   bool storesPending = false;
 #define SYNC_STORES() do { if (storesPending) { SECTION_COUNT(w, 7); wave_fence(); storesPending = false; } } while (0)
@@ -268,7 +247,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   // poll behind a closed gate) are not events: their chains are caught up when the group next runs a tick
   // (catch_up) and once more when the launch ends, so every word is as the tick-by-tick order leaves it.
   const int tEnd = t0 + nticks;
-#define MS_TICK(ms) (((ms) + (RG_TICK_MS - 1)) / RG_TICK_MS)    /* first tick whose time is >= ms (ms >= 0) */
+#define MS_TICK(ms) ((int)(((unsigned)((ms) > 0 ? (ms) : 0) + (unsigned)(RG_TICK_MS - 1)) / (unsigned)RG_TICK_MS))    /* first tick whose time is >= ms (ms >= 0) */
 #define gNextStart coldLds[CD_N + 2][threadIdx.x]
 #define gChurnNext churnNext[gLoc]
   {
@@ -470,10 +449,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     // (groups without a control event in this tick run theirs up to this tick at the same time)
     if ((c.partPeriod > 0 || c.churnPeriod > 0) && wave_any(partNow || churnNow)) client_starts(run, (partNow || churnNow) ? t - 1 : t);
     if (partNow) {
-      unsigned ep = (unsigned)gPartEpoch;
-      r.set(F_SIDE, (stream_hash(key, STREAM_PART, ep, (unsigned)peer + 1) & 1) != 0);
-      u64 h = stream_hash(key, STREAM_PART, ep, 0);
-      gPartNext = t + c.partPeriod + (c.partJitter > 0 ? (int)mod_u64(h, (unsigned)c.partJitter) : 0);
+      // one hash per reshuffle: bit p = side of peer p, the upper half scaled to the jitter
+      const u64 h = stream_hash(key, STREAM_PART, (unsigned)gPartEpoch, 0);
+      r.set(F_SIDE, (((unsigned)h >> peer) & 1u) != 0);
+      gPartNext = t + c.partPeriod + (int)(((u64)(unsigned)(h >> 32) * (u64)(unsigned)c.partJitter) >> 32);
       gPartEpoch++;
     }
     if (c.churnPeriod > 0 && wave_any(churnNow)) { storesPending = true; verify_applied(churnNow && r.has(F_DEAD)); }   // a restart replays the log
@@ -576,10 +555,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
             r.timer = now;
             if (!r.has(F_RESTART)) r.term++; else r.flags &= ~F_RESTART;
             r.vote = peer;
-            persist(r, L, w);
+            persist(r, L, w);                                       // raft.go:576
             aLli = r.commit;
             aLlt = r.cd(CD_CTERM);                                  // logs[commitIndex].Term, raft.go:583
-            persist(r, L, w);
+            ctr_add(w, RG_C_PERSISTS, 1);                           // raft.go:589: the same state once more
             ctr_add(w, RG_C_RV_ROUNDS, 1);
           }
           const bool inR = G.ballot(wantRV) != 0;
@@ -589,8 +568,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           if (wantRV) r.cd(CD_ROUNDSEQ) = (int)(seq + 1u);
           const bool tgt = inR && valid && peer != s;
           const bool reach = tgt && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
-          const u64 delays = round_delays(c, key, sIdx, seq);
-          const int outW = tgt ? net_outcome(c, key, reach, s, peer, seq, delays) : 0;
+          int cost = 0;
+          const int outW = tgt ? net_outcome(c, key, reach, s, peer, seq, cost) : 0;
           const int out = outW & 3;
           VoteDecision d; d.rTerm = 0; d.touch = d.raise = d.grant = false;
           if (out != 0) d = decide_vote(r, r.cd(CD_CTERM), T, s, lli, llt);
@@ -603,9 +582,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
             if (wasLead && d.touch && myPos > sPos && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok), grantM = G.ballot(ok && d.grant);
-          const unsigned failM = G.ballot(called && (outW & NET_FAIL_FAST));
-          if constexpr (EXT) atomicAdd((unsigned *)&coldLds[CD_N + 6][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
-          const int busy = round_busy<P>(calledM, okM, failM, delays);
+          if constexpr (EXT) atomicAdd((unsigned *)&coldLds[CD_N + 9][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
+          const int busy = G.gsum(called ? cost : 0);
           bool won = false;
           if (wantRV) {
             ctr_add(w, RG_C_RPC_SENT, (unsigned)__popc(calledM));
@@ -697,7 +675,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           // ---------------- one replication round, raft.go:423-512
           const bool inR = G.ballot(wantAE) != 0;
           const int T = G.shfl(r.term, sIdx), lenS = G.shfl(r.logLen, sIdx), commitS = G.shfl(r.commit, sIdx);
-          const int lastTermS = G.shfl(r.cd(CD_LASTTERM), sIdx), firstOwnS = G.shfl(r.cd(CD_FIRSTOWN), sIdx), cTermS = G.shfl(r.cd(CD_CTERM), sIdx);
+          const int lastTermS = r.cold[CD_LASTTERM * 256 + (sIdx - peer)], firstOwnS = r.cold[CD_FIRSTOWN * 256 + (sIdx - peer)];   // the sender's words, read in place
+          const int cTermS = r.cold[CD_CTERM * 256 + (sIdx - peer)];
           const unsigned seq = (unsigned)r.cold[CD_ROUNDSEQ * 256 + (sIdx - peer)];
           const unsigned fS = G.shflu(r.flags, sIdx);
           if (wantAE) r.cd(CD_ROUNDSEQ) = (int)(seq + 1u);
@@ -712,8 +691,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           const int firstOv = ovm ? (__ffs((int)ovm) - 1) : NONE;
           const bool tgt2 = tgt && peer < firstOv;
           const bool reach = tgt2 && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
-          const u64 delays = round_delays(c, key, sIdx, seq);
-          const int outW = tgt2 ? net_outcome(c, key, reach, s, peer, seq, delays) : 0;
+          int cost = 0;
+          const int outW = tgt2 ? net_outcome(c, key, reach, s, peer, seq, cost) : 0;
           const int out = outW & 3;
           const int prev = nx - 1, k = lenS - nx;
           AppendDecision d; d.rTerm = 0; d.ct = 0; d.ci = 0; d.touch = d.match = false;
@@ -822,8 +801,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
               if (commitS > r.commit) r.commit = (r.logLen - 1 < commitS) ? r.logLen - 1 : commitS;
               if (r.commit > r.logLen - 1) gfl |= RG_FLAG_REF_PANIC;
               if (r.commit != oldCommit || nx <= r.commit) {          // the entry at commitIndex is new or was rewritten
+                // (the leader's word only stands for an entry this very request carried: this reference does not keep
+                // logs that agree at PrevLogIndex equal below it, raft.go:218-219 elects on commitIndex)
                 if (r.commit == lenS - 1) r.cd(CD_CTERM) = r.cd(CD_LASTTERM);
-                else if (r.commit == commitS && commitS < lenS) r.cd(CD_CTERM) = cTermS;
+                else if (nx <= r.commit && r.commit == commitS && commitS < lenS) r.cd(CD_CTERM) = cTermS;
                 else { wave_fence(); r.cd(CD_CTERM) = *lg.termp(r.commit < L ? r.commit : L - 1, peer); WAIT_LOADS(); }
               }
               persist(r, L, w);
@@ -834,8 +815,9 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
             if (wasLead && myPos > sPos && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
           }
           // the leader's handling of each reply, done by the replying lane
+          bool matchMoved = false;
           if (ok && b != peer) {
-            if (d.match) { cNext = lenS; cMatch = lenS - 1; matchRow(sIdx * PP + peer) = cMatch; }
+            if (d.match) { matchMoved = cMatch != lenS - 1; cNext = lenS; cMatch = lenS - 1; matchRow(sIdx * PP + peer) = cMatch; }
             else cNext = d.ci;                                       // raft.go:493-505; the walk over the leader's log follows
             nextRow(sIdx * PP + peer) = cNext;
           }
@@ -859,12 +841,11 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
             }
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
-          const unsigned failM = G.ballot(called && (outW & NET_FAIL_FAST));
           if constexpr (EXT) {   // wire bytes: summed per target lane in LDS words of its own, added to the counters when the launch ends
-            atomicAdd((unsigned *)&coldLds[CD_N + 6][tid], called ? (unsigned)RG_APPEND_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_APPEND_REPLY_BYTES : 0u) : 0u);
-            atomicAdd((unsigned *)&coldLds[CD_N + 7][tid], (called && k > 0) ? (unsigned)k : 0u);
+            atomicAdd((unsigned *)&coldLds[CD_N + 9][tid], called ? (unsigned)RG_APPEND_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_APPEND_REPLY_BYTES : 0u) : 0u);
+            atomicAdd((unsigned *)&coldLds[CD_N + 10][tid], (called && k > 0) ? (unsigned)k : 0u);
           }
-          const int busy = round_busy<P>(calledM, okM, failM, delays);
+          const int busy = G.gsum(called ? cost : 0);
           int rTermB = 0;
           if (wave_any(b < NONE)) rTermB = G.shfl(d.rTerm, b < NONE ? b : 0);
           // Would the commit rule (raft.go:400-416) move commitIndex with the matchIndex row as this round leaves it?
@@ -875,11 +856,14 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           {
             const bool folR = inR && valid && peer != s;
             ruleOpen = G.ballot(folR && cOwner != s) != 0;       // a follower the round did not reach: decided at the evaluation
-            const int mv = folR ? cMatch : -1;
-            int ge = 0;
+            // (the rule was evaluated right before the round: with no matchIndex moved it finds what it found then)
+            if (wave_any(matchMoved)) {
+              const int mv = folR ? cMatch : -1;
+              int ge = 0;
 #pragma unroll
-            for (int u = 0; u < P; u++) ge += G.shfl(mv, u) >= mv ? 1 : 0;
-            nAfter = G.gmax((folR && ge >= P / 2) ? mv : 0);
+              for (int u = 0; u < P; u++) ge += G.shfl(mv, u) >= mv ? 1 : 0;
+              nAfter = G.gmax((folR && ge >= P / 2) ? mv : 0);
+            }
           }
           if (wantAE) {
             ctr_add(w, RG_C_RPC_SENT, (unsigned)__popc(calledM));
@@ -1037,10 +1021,13 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 #undef RING_PUSH
   const int startSeqOut = gStartSeq, partEpochOut = gPartEpoch, partNextOut = gPartNext, recMaxOut = gRecMax;
   if (EXT && c.acctBytes) {
-    if (coldLds[CD_N + 6][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 6][threadIdx.x]);
-    if (coldLds[CD_N + 7][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 7][threadIdx.x]);
+    if (coldLds[CD_N + 9][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 9][threadIdx.x]);
+    if (coldLds[CD_N + 10][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 10][threadIdx.x]);
   }
 #undef gStartSeq
+#undef cOwner
+#undef cNext
+#undef cMatch
 #undef lVerified
 #undef gPartNext
 #undef gRecMax

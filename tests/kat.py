@@ -451,10 +451,34 @@ def apply_ring_overrun_is_reported(mk):
         assert err.status == _abi.ERR_STATE
 
 
+def vote_test_reads_the_voters_own_entry(mk):
+    """raft.go:218: the voter compares with logs[commitIndex].Term of ITS OWN log.  This reference elects on
+    commitIndex, so two logs that agree at PrevLogIndex may differ below it; when a heartbeat only raises the
+    follower's commitIndex (raft.go:293-299, no entry carried) the term at the new commitIndex is the follower's,
+    not the leader's.  Leader terms [0,1,2,3,3], followers [0,1,1,3,3], PrevLogIndex 4 matches, LeaderCommit 2:
+    the followers then grant a candidate with (LastLogIndex 2, LastLogTerm 1) -- 1 >= their own term 1 at
+    index 2, though the leader holds term 2 there."""
+    e = mk(n_groups=1, n_peers=3, log_cap=16, seed=1)
+    e.step(30)
+    assert e.get_state(0, 0) == (1, True)
+    _set_log(e, 0, 0, [0, 1, 2, 3, 3], term=4, commit=2)      # no entry of term 4: the commit rule stays put (raft.go:402)
+    for p in (1, 2):
+        _set_log(e, 0, p, [0, 1, 1, 3, 3], commit=1)
+    nx = e.read("nextindex")
+    nx[0, 0, :] = 5
+    e.write("nextindex", nx)
+    _put(e, "hbtimer", 0, 0, -1000)
+    e.step(2)
+    assert e.read("commit")[0].tolist() == [2, 2, 2] and e.read("loglen")[0].tolist() == [5, 5, 5]
+    assert e.read("term")[0].tolist() == [4, 4, 4]
+    assert e.request_vote(0, 1, 5, 2, 2, 1) == (5, True)
+    assert e.request_vote(0, 2, 5, 1, 1, 1) == (5, False)     # LastLogIndex 1 < commitIndex 2 at equal terms
+
+
 CASES = {f.__name__: f for f in (
     boot_and_three_starts, conflict_reply, append_truncates_unconditionally, leader_backoff, commit_rule,
     vote_compares_commit_index, restore_repersists_one_entry, start_on_isolated_leader, stop_rule,
     applied_entry_overwritten, same_term_vote_request_demotes_leader, candidate_steps_down_without_adopting_term,
     leader_adopts_term_keeps_vote, votes_are_counted_per_reply, late_vote_replies_are_lost,
     failed_candidate_retries_same_term, rng_draw_points, apply_stream_keeps_what_was_applied,
-    apply_ring_overrun_is_reported)}
+    apply_ring_overrun_is_reported, vote_test_reads_the_voters_own_entry)}
