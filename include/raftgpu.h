@@ -231,6 +231,17 @@ int rg_restart(rg_engine *e, int32_t group, int32_t peer);
 int rg_set_unreliable(rg_engine *e, int32_t req_drop_permille,
                       int32_t reply_drop_permille, int32_t reply_delay_permille);
 
+/* The same for ONE group: every tester config of the reference owns its network (config.go:70, 288-294), so a
+ * host that runs one config per group sets them per group.  A group without a call of its own uses the engine's
+ * rates; rg_reset_groups and rg_reset drop the group's own. */
+int rg_set_unreliable_group(rg_engine *e, int32_t group, int32_t req_drop_permille,
+                            int32_t reply_drop_permille, int32_t reply_delay_permille);
+/* make_config (config.go:60-96) inside a running engine: the listed groups (no repeats) get fresh peers -- Make with
+ * empty Persisters at the current tick, all connected -- a fresh tester record, cleared flags and logs, and fresh
+ * apply channels (ApplyMsgs of the old peers that were not drained are dropped).  Other groups are not touched;
+ * counters keep counting. */
+int rg_reset_groups(rg_engine *e, const int32_t *groups, int64_t n);
+
 /* applyCh (raft.go:672-688): copies the ApplyMsgs the (group, peer) slot emitted since the last drain into buf,
  * in the order and with the commands of the moment they were emitted (raft.go:680-684): an entry applied and later
  * overwritten in the log is delivered as it was applied, and a peer restarted in between (by rg_restart or by the

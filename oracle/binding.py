@@ -42,6 +42,8 @@ def load(path=None):
         "ro_set_connected": ([vp, i32, i32, i32], C.c_int), "ro_set_side": ([vp, i32, i32, i32], C.c_int),
         "ro_crash": ([vp, i32, i32], C.c_int), "ro_restart": ([vp, i32, i32], C.c_int),
         "ro_set_unreliable": ([vp, i32, i32, i32], C.c_int),
+        "ro_set_unreliable_group": ([vp, i32, i32, i32, i32], C.c_int),
+        "ro_reset_groups": ([vp, P(i32), i64], C.c_int),
         "ro_rpc_request_vote": ([vp, i32, i32, P(VoteArgs), P(VoteReply)], C.c_int),
         "ro_rpc_append_entries": ([vp, i32, i32, P(AppendArgs), P(i32), P(C.c_uint64), P(AppendReply)], C.c_int),
         "ro_read_state": ([vp, i32, vp, i64], C.c_int), "ro_write_state": ([vp, i32, vp, i64], C.c_int),
@@ -121,6 +123,13 @@ class OracleEngine(EngineBase):
 
     def append_entries_batch(self, groups, peers, reqs):
         return [self.append_entries(g, p, *q) for g, p, q in zip(groups, peers, reqs)]
+
+    def set_unreliable_group(self, g, req_drop=100, reply_drop=100, reply_delay=0):
+        self._check(self._lib.ro_set_unreliable_group(self._h, g, req_drop, reply_drop, reply_delay), "set_unreliable_group")
+
+    def reset_groups(self, groups):
+        a = (C.c_int32 * len(groups))(*[int(g) for g in groups])
+        self._check(self._lib.ro_reset_groups(self._h, a, len(groups)), "reset_groups")
 
     def start_batch(self, groups, peers, cmds):
         return [self.start(int(g), int(p), int(c)) for g, p, c in zip(groups, peers, cmds)]

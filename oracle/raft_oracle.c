@@ -68,6 +68,7 @@ typedef struct {
   uint64_t key;          /* per-group stream key */
   int32_t startSeq, partNext, partEpoch, recMax;
   uint32_t flags;
+  int32_t netOwn, reqDrop, replyDrop, replyDelay;   /* the group's own net rates (config.go:288-294), when netOwn */
   uint64_t *applyRec;    /* first command applied at each index, config.go:177-185 */
 } group_t;
 
@@ -249,17 +250,19 @@ static int net_outcome(const ro_engine *e, const group_t *g, int s, int j, uint3
   *cost = RG_RPC_WAIT_MS;
   *wire = 0;                      /* does the reply travel (and count its bytes, labrpc.go:286-290), in time or not */
   if (!(a->connected && b->connected && a->side == b->side) || b->dead) return NET_LOST;
-  const rg_config *cf = &e->cfg;
-  if (cf->req_drop_permille == 0 && cf->reply_drop_permille == 0 && cf->reply_delay_permille == 0) { *cost = 0; *wire = 1; return NET_OK; }
+  const int32_t reqDrop = g->netOwn ? g->reqDrop : e->cfg.req_drop_permille;
+  const int32_t replyDrop = g->netOwn ? g->replyDrop : e->cfg.reply_drop_permille;
+  const int32_t replyDelay = g->netOwn ? g->replyDelay : e->cfg.reply_delay_permille;
+  if (reqDrop == 0 && replyDrop == 0 && replyDelay == 0) { *cost = 0; *wire = 1; return NET_OK; }
   /* one hash per Call: 16 bits each for the two drop draws and the reordering draw, 8 bits for the delay */
   uint64_t h = stream_hash(g->key, STREAM_NET, ((uint32_t)s << 8) | (uint32_t)j, seq);
   int32_t d = (int32_t)((((h >> 48) & 0xFF) * RG_NET_DELAY_SPAN_MS) >> 8);                   /* :222, 0..26 */
   int32_t back = d < RG_RPC_WAIT_MS ? d : RG_RPC_WAIT_MS;           /* Call returns after d ms; the select gives up at 25 */
-  if (permille_of((uint32_t)(h & 0xFFFF)) < cf->req_drop_permille) { *cost = back; return NET_LOST; }   /* :226-229 */
-  *wire = !(permille_of((uint32_t)((h >> 16) & 0xFFFF)) < cf->reply_drop_permille);           /* :273 */
+  if (permille_of((uint32_t)(h & 0xFFFF)) < reqDrop) { *cost = back; return NET_LOST; }   /* :226-229 */
+  *wire = !(permille_of((uint32_t)((h >> 16) & 0xFFFF)) < replyDrop);           /* :273 */
   if (!*wire) { *cost = back; return NET_REPLY_LOST; }               /* :273-275 */
   if (d >= RG_RPC_WAIT_MS) return NET_REPLY_LOST;                    /* handler runs, the sender has given up */
-  if (permille_of((uint32_t)((h >> 32) & 0xFFFF)) < cf->reply_delay_permille) return NET_REPLY_LOST;  /* :276-285 */
+  if (permille_of((uint32_t)((h >> 32) & 0xFFFF)) < replyDelay) return NET_REPLY_LOST;  /* :276-285 */
   *cost = d;
   return NET_OK;
 }
@@ -605,23 +608,27 @@ static void tick_group(ro_engine *e, ctr_t *c, group_t *g, int32_t tick) {
 }
 
 /* ---------------- engine lifecycle -------------------------------------- */
-static void init_group(ro_engine *e, group_t *g, int64_t ggid) {
+/* make_config, config.go:60-96: fresh peers with empty Persisters, booted at tick nowTick */
+static void init_group(ro_engine *e, group_t *g, int64_t ggid, int32_t nowTick) {
   ctr_t scratch; memset(&scratch, 0, sizeof scratch);
   g->key = group_key(e->cfg.seed, ggid);
   g->startSeq = 0; g->partEpoch = 0; g->recMax = 0; g->flags = 0;
-  g->partNext = e->cfg.part_period > 0 ? e->cfg.part_period : 0;
+  g->netOwn = 0; g->reqDrop = g->replyDrop = g->replyDelay = 0;
+  g->partNext = e->cfg.part_period > 0 ? nowTick + e->cfg.part_period : 0;
   memset(g->applyRec, 0, sizeof(uint64_t) * (size_t)e->L);
   for (int p = 0; p < e->P; p++) {
     peer_t *rf = &g->peer[p];
     int32_t *lt = rf->logTerm, *st = rf->snapTerm_; uint64_t *lc = rf->logCmd, *sc = rf->snapCmd_;
     rg_apply_msg *ring = rf->applyRing;
+    const uint32_t head = nowTick ? rf->applyHead : 0;    /* a reset group gets new apply channels: nothing pending */
     memset(rf, 0, sizeof *rf);
     rf->logTerm = lt; rf->snapTerm_ = st; rf->logCmd = lc; rf->snapCmd_ = sc; rf->applyRing = ring;
+    rf->applyHead = rf->applyDrained = head;
     memset(lt, 0, sizeof(int32_t) * (size_t)e->L); memset(st, 0, sizeof(int32_t) * (size_t)e->L);
     memset(lc, 0, sizeof(uint64_t) * (size_t)e->L); memset(sc, 0, sizeof(uint64_t) * (size_t)e->L);
     rf->connected = 1; rf->side = 0;
     rf->snapSync = 1;          /* entry 0 is the same sentinel in every array */
-    make_peer(e, &scratch, g, p, 0);
+    make_peer(e, &scratch, g, p, nowTick * RG_TICK_MS);
   }
 }
 
@@ -660,7 +667,7 @@ ro_engine *ro_create(const rg_config *cfg) {
 void ro_reset(ro_engine *e) {
   e->now = 0;
   memset(e->counters, 0, sizeof e->counters);
-  for (int g = 0; g < e->G; g++) init_group(e, &e->groups[g], e->cfg.group_base + g);
+  for (int g = 0; g < e->G; g++) init_group(e, &e->groups[g], e->cfg.group_base + g, 0);
 }
 
 void ro_destroy(ro_engine *e) {
@@ -751,6 +758,19 @@ int ro_restart(ro_engine *e, int32_t g, int32_t p) {
   ctr_t c; memset(&c, 0, sizeof c);
   start1(e, &c, &e->groups[g], p, (int32_t)e->now * RG_TICK_MS);
   add_counters(e, &c);
+  return RG_OK;
+}
+int ro_set_unreliable_group(ro_engine *e, int32_t g, int32_t a, int32_t b, int32_t d) {
+  if (!e || a < 0 || b < 0 || d < 0 || a > 1000 || b > 1000 || d > 1000) return RG_ERR_ARG;
+  if (g < 0 || g >= e->G) return RG_ERR_RANGE;
+  group_t *gr = &e->groups[g];
+  gr->netOwn = 1; gr->reqDrop = a; gr->replyDrop = b; gr->replyDelay = d;
+  return RG_OK;
+}
+int ro_reset_groups(ro_engine *e, const int32_t *groups, int64_t n) {
+  if (!e || n < 0 || (n > 0 && !groups)) return RG_ERR_ARG;
+  for (int64_t i = 0; i < n; i++) if (groups[i] < 0 || groups[i] >= e->G) return RG_ERR_RANGE;
+  for (int64_t i = 0; i < n; i++) init_group(e, &e->groups[groups[i]], e->cfg.group_base + groups[i], (int32_t)e->now);
   return RG_OK;
 }
 int ro_set_unreliable(ro_engine *e, int32_t a, int32_t b, int32_t d) {

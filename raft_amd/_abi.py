@@ -109,7 +109,7 @@ def make_config(**kw):
 EXPORTS = [
     "rg_device_count", "rg_version", "rg_strerror", "rg_create", "rg_destroy", "rg_reset", "rg_set_stream",
     "rg_step", "rg_step_noalloc", "rg_sync", "rg_now", "rg_step_time_ms", "rg_start", "rg_start_batch", "rg_get_state",
-    "rg_set_connected", "rg_set_side", "rg_crash", "rg_restart", "rg_set_unreliable", "rg_drain_applied",
+    "rg_set_connected", "rg_set_side", "rg_crash", "rg_restart", "rg_set_unreliable", "rg_set_unreliable_group", "rg_reset_groups", "rg_drain_applied",
     "rg_snapshot_export", "rg_snapshot_import", "rg_rpc_request_vote", "rg_rpc_append_entries",
     "rg_read_state", "rg_write_state", "rg_state_hash", "rg_counters", "rg_rpc_bytes", "rg_safety_check", "rg_safety_flags",
     "rg_device_buffers",
@@ -150,6 +150,8 @@ def load_library(path=None):
         "rg_crash": ([vp, i32, i32], C.c_int),
         "rg_restart": ([vp, i32, i32], C.c_int),
         "rg_set_unreliable": ([vp, i32, i32, i32], C.c_int),
+        "rg_set_unreliable_group": ([vp, i32, i32, i32, i32], C.c_int),
+        "rg_reset_groups": ([vp, P(i32), i64], C.c_int),
         "rg_drain_applied": ([vp, i32, i32, P(ApplyMsgC), i64, P(i64)], C.c_int),
         "rg_snapshot_export": ([vp, i32, i32, vp, i64, P(i64)], C.c_int),
         "rg_snapshot_import": ([vp, i32, i32, vp, i64], C.c_int),

@@ -85,6 +85,7 @@ struct rg_engine {
   bool derivedDirty, syncDirty;
   std::vector<unsigned> drained;  // per (g,p): ApplyMsgs handed out by rg_drain_applied so far
   rg_apply_msg *applyRing; unsigned *applyHead; int applyCap;
+  unsigned *netCfg;               // device: per-group net rates, allocated by the first rg_set_unreliable_group
   std::mutex mu;
   // staging
   HostCmd *dCmd; size_t dCmdCap;
@@ -201,6 +202,7 @@ static int init_state(rg_engine *e) {
   HIPCHK(hipMemsetAsync(S.counters, 0, RG_CTR_SLOTS * 8, st));
   HIPCHK(hipMemsetAsync(S.flagSummary, 0, 8, st));
   if (e->applyCap > 0) HIPCHK(hipMemsetAsync(e->applyHead, 0, (size_t)e->nLanes * sizeof(unsigned), st));
+  if (e->netCfg) HIPCHK(hipMemsetAsync(e->netCfg, 0, (size_t)e->Gpad * sizeof(unsigned), st));
   HIPCHK(hipStreamSynchronize(st));
   e->now = 0; e->derivedDirty = false; e->syncDirty = false;
   std::fill(e->drained.begin(), e->drained.end(), 0);
@@ -274,7 +276,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (rc == RG_OK) rc = dalloc(e, &S.flagSummary, (size_t)2);
   if (rc != RG_OK) { free_engine(e); return rc; }
   e->drained.assign((size_t)e->G * e->P, 0);
-  e->applyCap = cfg->apply_ring_cap; e->applyRing = nullptr; e->applyHead = nullptr;
+  e->applyCap = cfg->apply_ring_cap; e->applyRing = nullptr; e->applyHead = nullptr; e->netCfg = nullptr;
   if (e->applyCap > 0) {
     rc = dalloc(e, &e->applyRing, (size_t)e->G * e->P * e->applyCap);
     if (rc == RG_OK) rc = dalloc(e, &e->applyHead, (size_t)e->nLanes);
@@ -287,7 +289,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     if (rc != RG_OK) { free_engine(e); return rc; }
   }
   e->H.relay = e->relay; e->H.relayStage = e->relayStage;
-  e->H.applyRing = e->applyRing; e->H.applyHead = e->applyHead; e->H.applyCap = e->applyCap;
+  e->H.applyRing = e->applyRing; e->H.applyHead = e->applyHead; e->H.applyCap = e->applyCap; e->H.netCfg = nullptr;
   e->H.logRows = S.logRows; e->H.snapRows = S.snapRows; e->H.nextIdx = S.nextIdx; e->H.matchIdx = S.matchIdx; e->H.applyRec = S.applyRec;
   if (dalloc(e, &e->dS, 1) != RG_OK || hipMemcpy(e->dS, &e->S, sizeof(DevPtrs), hipMemcpyHostToDevice) != hipSuccess) { free_engine(e); return RG_ERR_NOMEM; }
   rc = init_state(e);
@@ -381,7 +383,7 @@ static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage)
   if (getenv("RAFTGPU_TRACE_LAUNCH")) fprintf(stderr, "raftgpu: k_tick ticks=%d blocks=%d relay_sets=%d relay_chunk=%d groups_per_wave=%d\n", n_ticks, blocks, dc.relaySets, dc.relayChunk, dc.gwA);
   const DevPtrs *dS = e->dS;
 #define TICK_LAUNCH(PEERS) do { \
-    if (dc.acctBytes || H.applyCap > 0) hipLaunchKernelGGL((k_tick<PEERS, true>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
+    if (dc.acctBytes || H.applyCap > 0 || H.netCfg) hipLaunchKernelGGL((k_tick<PEERS, true>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
     else hipLaunchKernelGGL((k_tick<PEERS, false>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)
   switch (e->P) {
   case 2: TICK_LAUNCH(2); break;
@@ -586,6 +588,61 @@ extern "C" int rg_set_unreliable(rg_engine *e, int32_t a, int32_t b, int32_t d) 
   return RG_OK;
 }
 
+struct TmpBuf {
+  std::vector<void *> p;
+  ~TmpBuf() { for (void *q : p) hipFree(q); }
+  template <typename T> T *get(size_t n) { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return (T *)q; }
+};
+
+// Network.Reliable / LongReordering of ONE tester config (config.go:288-294: every config owns its labrpc.Network).
+extern "C" int rg_set_unreliable_group(rg_engine *e, int32_t g, int32_t a, int32_t b, int32_t d) {
+  LOCK(e);
+  if (a < 0 || b < 0 || d < 0 || a > 1000 || b > 1000 || d > 1000) return RG_ERR_ARG;
+  if (g < 0 || g >= e->G) return RG_ERR_RANGE;
+  if (!e->netCfg) {
+    int rc = dalloc(e, &e->netCfg, (size_t)e->Gpad);
+    if (rc != RG_OK) return rc;
+    HIPCHK(hipMemsetAsync(e->netCfg, 0, (size_t)e->Gpad * sizeof(unsigned), e->stream));
+    e->H.netCfg = e->netCfg;
+  }
+  const unsigned w = 0x80000000u | (unsigned)a | ((unsigned)b << 10) | ((unsigned)d << 20);
+  HIPCHK(hipMemcpyAsync(e->netCfg + g, &w, 4, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return RG_OK;
+}
+
+// make_config (config.go:60-96) for groups of a running engine: fresh peers (empty Persisters, term 0, all
+// connected, side 0), fresh tester record and flags, the engine's net rates, booted at the current tick.
+extern "C" int rg_reset_groups(rg_engine *e, const int32_t *groups, int64_t n) {
+  LOCK(e);
+  if (n < 0 || (n > 0 && !groups)) return RG_ERR_ARG;
+  if (n == 0) return RG_OK;
+  for (int64_t i = 0; i < n; i++) {
+    if (groups[i] < 0 || groups[i] >= e->G) return RG_ERR_RANGE;
+    for (int64_t j = 0; j < i; j++) if (groups[j] == groups[i]) return RG_ERR_ARG;   // one block per group: no repeats
+  }
+  int rc = run_derive(e);
+  if (rc != RG_OK) return rc;
+  TmpBuf tb;
+  int *dg = tb.get<int>((size_t)n);
+  if (!dg) return RG_ERR_NOMEM;
+  HIPCHK(hipMemcpyAsync(dg, groups, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_reset_groups, dim3((unsigned)n), dim3(256), 0, e->stream, e->S, e->dc, e->PP, dg, (int)e->now);
+  HIPCHK(hipGetLastError());
+  const unsigned zero = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (e->netCfg) HIPCHK(hipMemcpyAsync(e->netCfg + groups[i], &zero, 4, hipMemcpyHostToDevice, e->stream));
+    if (e->applyCap > 0) {             // a new applyCh per peer: what the old peers emitted and nobody read is gone
+      unsigned heads[RG_MAX_PEERS];
+      HIPCHK(hipMemcpyAsync(heads, e->applyHead + (size_t)groups[i] * e->PP, (size_t)e->P * 4, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      for (int p = 0; p < e->P; p++) e->drained[(size_t)groups[i] * e->P + p] = heads[p];
+    }
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return RG_OK;
+}
+
 // ---- strided host <-> device copies of one column / word ------------------------
 static int d2h(rg_engine *e, void *dst, const void *src, size_t n) {
   HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, e->stream));
@@ -725,12 +782,6 @@ static void level_order(const int32_t *groups, int64_t n, std::vector<int> &orde
   }
   startOf[maxLevel + 1] = order.size();
 }
-
-struct TmpBuf {
-  std::vector<void *> p;
-  ~TmpBuf() { for (void *q : p) hipFree(q); }
-  template <typename T> T *get(size_t n) { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return (T *)q; }
-};
 
 extern "C" int rg_rpc_request_vote(rg_engine *e, int64_t n, const int32_t *groups, const int32_t *peers,
                                    const rg_vote_args *args, rg_vote_reply *replies) {

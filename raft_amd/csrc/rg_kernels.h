@@ -123,21 +123,21 @@ __global__ void k_rpc_append(DevPtrs S, DevCfg c, int PP, const int *groups, con
   if (threadIdx.x < RG_N_COUNTERS && sctr.c[threadIdx.x]) atomicAdd((unsigned long long *)&S.counters[threadIdx.x], (unsigned long long)sctr.c[threadIdx.x]);
 }
 
-// Make for every peer (raft.go:526-568): every per-peer and per-group word of a fresh engine, one thread per lane.
+// Make (raft.go:700-731 with an empty Persister, and the head of election(), raft.go:538-547) for the peer of lane gl
+// at time nowTick: every per-peer word, the peer's rows of the leader matrices and, by peer 0, the group words.
 // Lanes past the last group or peer hold zeros.
-__global__ void k_init(DevPtrs S, DevCfg c, int PP, long long nLanes) {
-  long long gl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gl >= nLanes) return;
+__device__ static inline void init_lane(const DevPtrs &S, const DevCfg &c, int PP, long long gl, int nowTick) {
   const int g = (int)(gl / PP), p = (int)(gl % PP);
   const bool peer = g < c.G && p < c.P;
+  const int nowMs = peer ? nowTick * RG_TICK_MS : 0;
   int timeout = 0;
   if (peer && p != 0) {                                          // raft.go:545-547
     const u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
     const u64 h = stream_hash(key, STREAM_ELECTION, (unsigned)p, 0);
     timeout = (int)((unsigned)(h >> 32) % (unsigned)RG_TIMEOUT_SPAN_MS) + RG_TIMEOUT_BASE_MS;
   }
-  S.term[gl] = 0; S.vote[gl] = -1; S.commit[gl] = 0; S.applied[gl] = 0; S.timer[gl] = 0; S.hbTimer[gl] = 0;
-  S.elNext[gl] = 0; S.monNext[gl] = 0; S.roundSeq[gl] = 0; S.snapTerm[gl] = 0; S.snapVote[gl] = 0; S.snapLen[gl] = 0;
+  S.term[gl] = 0; S.vote[gl] = -1; S.commit[gl] = 0; S.applied[gl] = 0; S.timer[gl] = nowMs; S.hbTimer[gl] = nowMs;
+  S.elNext[gl] = nowMs; S.monNext[gl] = 0; S.roundSeq[gl] = 0; S.snapTerm[gl] = 0; S.snapVote[gl] = 0; S.snapLen[gl] = 0;
   S.lastTerm[gl] = 0; S.commitTerm[gl] = 0; S.applyHash[gl] = 0;
   S.flags[gl] = peer ? (int)F_CONNECTED : 0;
   S.logLen[gl] = peer; S.snapSync[gl] = peer; S.firstOwn[gl] = peer;
@@ -145,8 +145,30 @@ __global__ void k_init(DevPtrs S, DevCfg c, int PP, long long nLanes) {
   for (int q = 0; q < PP; q++) { S.nextIdx[gl * PP + q] = 0; S.matchIdx[gl * PP + q] = 0; }
   if (p == 0) {
     S.startSeq[g] = 0; S.partEpoch[g] = 0; S.recMax[g] = 0; S.gflags[g] = 0;
-    S.partNext[g] = g < c.G && c.partPeriod > 0 ? c.partPeriod : 0;
+    S.partNext[g] = g < c.G && c.partPeriod > 0 ? nowTick + c.partPeriod : 0;
   }
+}
+
+// Make for every peer of the engine at tick 0, one thread per lane.
+__global__ void k_init(DevPtrs S, DevCfg c, int PP, long long nLanes) {
+  long long gl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gl >= nLanes) return;
+  init_lane(S, c, PP, gl, 0);
+}
+
+// A fresh set of peers (config.go:60-96: a new tester config) in each listed group at tick nowTick: one block per
+// group; the lanes first, then the group's log rows, snapshot rows and tester record are cleared.
+__global__ void k_reset_groups(DevPtrs S, DevCfg c, int PP, const int *groups, int nowTick) {
+  const int g = groups[blockIdx.x];
+  if ((int)threadIdx.x < PP) init_lane(S, c, PP, (long long)g * PP + threadIdx.x, nowTick);
+  const size_t rowInts = (size_t)c.L * c.rowBytes / 4;
+  int *lr = (int *)(S.logRows + (size_t)g * c.L * c.rowBytes);
+  for (size_t i = threadIdx.x; i < rowInts; i += blockDim.x) lr[i] = 0;
+  if (S.snapRows) {
+    int *sr = (int *)(S.snapRows + (size_t)g * c.L * c.rowBytes);
+    for (size_t i = threadIdx.x; i < rowInts; i += blockDim.x) sr[i] = 0;
+  }
+  for (int i = threadIdx.x; i < c.L; i += blockDim.x) S.applyRec[(size_t)g * c.L + i] = 0;
 }
 
 // (re)build the derived words after the host wrote state directly

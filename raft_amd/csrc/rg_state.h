@@ -169,6 +169,7 @@ struct HotPtrs {
   rg_apply_msg *applyRing;       // [G * P][applyCap]: the ApplyMsgs each peer emitted, in order, slot = message number % applyCap
   unsigned *applyHead;           // [Gpad * PP], indexed like the per-peer words: messages emitted so far
   int applyCap;                  // 0: no ring (nobody reads applyCh from the host)
+  const unsigned *netCfg;        // [Gpad] per-group net rates (bit 31: set; 10 bits each: request drop, reply drop, reply delay), or null
 };
 
 __device__ static inline void ctr_add(WaveCtr *w, int which, unsigned v) { atomicAdd(&w->c[which], v); }

@@ -103,7 +103,10 @@ __device__ static inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_
 // works out its own share of the round's duration and the sender adds them up.
 #define NET_WIRE 4
 __device__ static inline int permille_of(unsigned field16) { return (int)((field16 * 1000u) >> 16); }
-__device__ static inline int net_outcome(const DevCfg &c, u64 key, bool reachable, int s, int j, unsigned seq, int &cost) {
+struct NetRates { int reqDrop, replyDrop, replyDelay; };     // the net model's three rates, permille
+// per-group override word: bit 31 set, then 10 bits each
+__device__ static inline NetRates unpack_rates(unsigned w) { NetRates n; n.reqDrop = (int)(w & 1023u); n.replyDrop = (int)((w >> 10) & 1023u); n.replyDelay = (int)((w >> 20) & 1023u); return n; }
+__device__ static inline int net_outcome(const NetRates &c, u64 key, bool reachable, int s, int j, unsigned seq, int &cost) {
   cost = RG_RPC_WAIT_MS;
   if (!reachable) return 0;
   if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) { cost = 0; return 2 | NET_WIRE; }
@@ -200,6 +203,12 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 #define rOff (gLocL * (unsigned)L)
 #define rec(i) recBlk[rOff + (unsigned)(i)]
   u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
+  // the net's rates: the engine's, or (extended instantiation) the group's own (Network.Reliable / LongReordering are
+  // per tester config in the reference, config.go:288-294, labrpc.go:169-181)
+  NetRates net; net.reqDrop = c.reqDrop; net.replyDrop = c.replyDrop; net.replyDelay = c.replyDelay;
+  if constexpr (EXT) {
+    if (H.netCfg) { const unsigned nw = H.netCfg[gq]; if (nw >> 31) net = unpack_rates(nw); }
+  }
 
   __shared__ int coldLds[CD_N + 9 + (EXT ? 2 : 0)][256];   // peer words, 5 group words, the checked-apply cursor, the lane's cache of one leader's nextIndex / matchIndex pair, per-lane byte sums
   __shared__ int churnNext[GPB];                              // per group: its next churn tick (written by all its lanes alike)
@@ -569,7 +578,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           const bool tgt = inR && valid && peer != s;
           const bool reach = tgt && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
           int cost = 0;
-          const int outW = tgt ? net_outcome(c, key, reach, s, peer, seq, cost) : 0;
+          const int outW = tgt ? net_outcome(net, key, reach, s, peer, seq, cost) : 0;
           const int out = outW & 3;
           VoteDecision d; d.rTerm = 0; d.touch = d.raise = d.grant = false;
           if (out != 0) d = decide_vote(r, r.cd(CD_CTERM), T, s, lli, llt);
@@ -692,7 +701,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           const bool tgt2 = tgt && peer < firstOv;
           const bool reach = tgt2 && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
           int cost = 0;
-          const int outW = tgt2 ? net_outcome(c, key, reach, s, peer, seq, cost) : 0;
+          const int outW = tgt2 ? net_outcome(net, key, reach, s, peer, seq, cost) : 0;
           const int out = outW & 3;
           const int prev = nx - 1, k = lenS - nx;
           AppendDecision d; d.rTerm = 0; d.ct = 0; d.ci = 0; d.touch = d.match = false;

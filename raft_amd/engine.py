@@ -104,6 +104,14 @@ class EngineBase(object):
     def set_unreliable(self, req_drop=100, reply_drop=100, reply_delay=0):
         self._check(self._fn("set_unreliable")(self._h, req_drop, reply_drop, reply_delay), "set_unreliable")
 
+    def set_unreliable_group(self, g, req_drop=100, reply_drop=100, reply_delay=0):
+        self._check(self._fn("set_unreliable_group")(self._h, g, req_drop, reply_drop, reply_delay), "set_unreliable_group")
+
+    def reset_groups(self, groups):
+        """Fresh peers, tester record and apply channels in the listed groups, booted at the current tick."""
+        a = (C.c_int32 * len(groups))(*[int(g) for g in groups])
+        self._check(self._fn("reset_groups")(self._h, a, len(groups)), "reset_groups")
+
     def snapshot_export(self, g, p):
         n = C.c_int64()
         self._check(self._fn("snapshot_export")(self._h, g, p, None, 0, C.byref(n)), "snapshot_export")

@@ -32,6 +32,7 @@ class Config(object):
         self.logs = [dict() for _ in range(self.n)]
         self.chans = [None] * self.n
         self.maxIndex = 0
+        self.longreordering = False
         self.setunreliable(unreliable)
         for i in range(self.n):
             self.start1(i)
@@ -90,19 +91,25 @@ class Config(object):
 
     # ---- connectivity (config.go:235-278) ----------------------------------
     def connect(self, i):
-        self.connected[i] = True
+        self.connected[i] = self.net.connected[i] = True
         self.engine.set_connected(self.group, i, True)
 
     def disconnect(self, i):
-        self.connected[i] = False
+        self.connected[i] = self.net.connected[i] = False
         self.engine.set_connected(self.group, i, False)
 
+    # every config owns its network (config.go:70, 288-298): the rates are the group's, not the engine's
     def setunreliable(self, unrel):
-        self.engine.set_unreliable(100 if unrel else 0, 100 if unrel else 0, 0)
         self.unreliable = unrel
+        self._rates()
 
     def setlongreordering(self, yes):
-        self.engine.set_unreliable(100 if self.unreliable else 0, 100 if self.unreliable else 0, 667 if yes else 0)
+        self.longreordering = yes
+        self._rates()
+
+    def _rates(self):
+        drop = 100 if self.unreliable else 0
+        self.engine.set_unreliable_group(self.group, drop, drop, 667 if self.longreordering else 0)
 
     def rpcTotal(self):
         return self.engine.counters()["rpc_sent"]

@@ -10,6 +10,9 @@ GetState, :377 Kill; src/raft/persister.go:20-70 Persister):
     rf.GetState() -> (term, isLeader)
     rf.Kill()
 
+`net.ends(i)[j].Call("Raft.RequestVote" | "Raft.AppendEntries", args, reply)` is the labrpc-shaped way to
+the exported handlers (reference: src/labrpc/labrpc.go:84-121, src/raft/raft.go:161-195).
+
 Time does not pass by itself: `net.advance(ticks)` steps the engine (every
 group it holds) and then delivers the ApplyMsgs each live peer emitted to its
 applyCh, in index order, as the reference's apply goroutine does
@@ -85,12 +88,82 @@ def decode_raft_state(blob):
     return term, vote, [(t, c) for t, _, c in ents]
 
 
+class RequestVoteArgs(object):
+    """reference: src/raft/raft.go:161-168"""
+    def __init__(self, Term=0, CandidateId=0, LastLogIndex=0, LastLogTerm=0):
+        self.Term, self.CandidateId, self.LastLogIndex, self.LastLogTerm = Term, CandidateId, LastLogIndex, LastLogTerm
+
+
+class RequestVoteReply(object):
+    """reference: src/raft/raft.go:174-177"""
+    def __init__(self, Term=0, VoteGranted=False):
+        self.Term, self.VoteGranted = Term, VoteGranted
+
+
+class AppendEntriesArgs(object):
+    """reference: src/raft/raft.go:179-186; Entries = [(term, command), ...]"""
+    def __init__(self, Term=0, LeaderId=0, PrevLogIndex=0, PrevLogTerm=0, Entries=(), LeaderCommit=0):
+        self.Term, self.LeaderId, self.PrevLogIndex, self.PrevLogTerm = Term, LeaderId, PrevLogIndex, PrevLogTerm
+        self.Entries, self.LeaderCommit = list(Entries), LeaderCommit
+
+
+class AppendEntriesReply(object):
+    """reference: src/raft/raft.go:188-195"""
+    def __init__(self, Term=0, Success=False, ConflictTerm=0, ConflictFirstIndex=0):
+        self.Term, self.Success, self.ConflictTerm, self.ConflictFirstIndex = Term, Success, ConflictTerm, ConflictFirstIndex
+
+
+class ClientEnd(object):
+    """The end server `me` uses to reach server `to` (reference: src/labrpc/labrpc.go:84-121).  Call returns
+    False when the network loses the request -- an end of a disconnected server (config.go:235-278) or a killed
+    target (labrpc.go:268-272).  A reply decodes the way gob does: zero fields of the wire value leave the
+    caller's object alone (labgob.go:116-121), which the reference's election loop relies on (raft.go:585-616)."""
+
+    def __init__(self, net, me, to):
+        self.net, self.me, self.to = net, me, to
+
+    def Call(self, svcMeth, args, reply):
+        net = self.net
+        target = net.rafts[self.to]
+        if not (net.connected[self.me] and net.connected[self.to]) or target is None or target.killed():
+            return False
+        eng, g = net.engine, net.group
+        if svcMeth == "Raft.RequestVote":
+            term, granted = eng.request_vote(g, self.to, args.Term, args.CandidateId, args.LastLogIndex, args.LastLogTerm)
+            if term != 0:
+                reply.Term = term
+            if granted:
+                reply.VoteGranted = True
+            return True
+        if svcMeth == "Raft.AppendEntries":
+            entries = [(t, net.handle_for(c)) for t, c in args.Entries]
+            term, ok, ct, cf = eng.append_entries(g, self.to, args.Term, args.LeaderId, args.PrevLogIndex, args.PrevLogTerm,
+                                                  entries, args.LeaderCommit)
+            if term != 0:
+                reply.Term = term
+            if ok:
+                reply.Success = True
+            if ct != 0:
+                reply.ConflictTerm = ct
+            if cf != 0:
+                reply.ConflictFirstIndex = cf
+            return True
+        return False                     # unknown service or method (labrpc.go:440-442)
+
+
 class Network(object):
     """One Raft group of the engine, standing in for the labrpc.Network a
-    tester builds per group (reference: src/raft/config.go:70)."""
+    tester builds per group (reference: src/raft/config.go:70).  On an engine that has already run, the group
+    is first given fresh peers (rg_reset_groups): a new tester config starts from Make, not from whatever the
+    group's previous peers left."""
 
-    def __init__(self, engine, group=0):
+    def __init__(self, engine, group=0, reset=None):
         self.engine, self.group, self.n = engine, group, engine.P
+        if reset is None:
+            reset = engine.now() > 0
+        if reset:
+            engine.reset_groups([group])
+        self.connected = [True] * self.n
         self.rafts = [None] * self.n
         self.persisters = [None] * self.n
         self.apply_chs = [None] * self.n
@@ -132,6 +205,9 @@ class _Ends(object):
 
     def __len__(self):
         return self.net.n
+
+    def __getitem__(self, j):
+        return ClientEnd(self.net, self.me, j)
 
 
 class Raft(object):
@@ -175,7 +251,7 @@ def Make(peers, me, persister, applyCh):
     if old is not None and not old.killed():
         old.Kill()
     blob = persister.ReadRaftState() if persister is not None else b""
-    fresh = not net._booted[me] and not blob and eng.now() == 0
+    fresh = not net._booted[me] and not blob          # the peer rg_create / rg_reset_groups made is this one
     if persister is None:
         persister = Persister()
     persister._bound = (net, me)

@@ -463,3 +463,76 @@ ALL = {
     "UnreliableAgree2C": unreliable_agree_2c, "Figure8Unreliable2C": figure8_unreliable_2c,
     "ReliableChurn2C": lambda mk: churn_2c(mk, False), "UnreliableChurn2C": lambda mk: churn_2c(mk, True),
 }
+
+
+# ---- several tester configs on one engine, and the labrpc-shaped ends -------------------------------------------
+
+def two_configs_on_one_engine(make_engine):
+    """config.go:60-96: every make_config builds fresh peers on a network of its own.  Two configs share one
+    engine here: the second is made 3 s after the first, its peers are fresh Makes at that moment (term 0, peer 0
+    with timeout 0 wins term 1, raft.go:545), and its network is reliable while the first one's is not."""
+    eng = make_engine(n_groups=4, n_peers=3, log_cap=128, seed=3, account_bytes=1, apply_ring_cap=128)
+    a = Config(eng, 0, unreliable=True)
+    for i in range(3):
+        a.one(100 + i, 3, True)
+    a.advance(300 - (eng.now() % 300))
+    t_b = eng.now()
+    assert eng.read("term")[2].max() >= 1                   # group 2 has been running all along ...
+    b = Config(eng, 2, unreliable=False)
+    assert eng.read("term")[2].tolist() == [0, 0, 0]        # ... and starts over for its new config
+    assert eng.read("loglen")[2].tolist() == [1, 1, 1] and eng.read("timer")[2].tolist() == [t_b * 10] * 3
+    assert eng.read("term")[0].min() >= 1                   # the first config is not touched
+    assert b.checkOneLeader() == 0 and b.checkTerms() == 1
+    before = eng.counters()
+    assert b.one(11, 3, False) == 1
+    assert a.one(200, 3, True) == 4
+    assert b.one(12, 3, False) == 2
+    assert b.logs[0] == {1: 11, 2: 12} and [a.logs[0][i] for i in (1, 2, 3, 4)] == [100, 101, 102, 200]
+    assert eng.safety_check() == (0, 0)
+    return eng
+
+
+def labrpc_ends_reach_the_handlers(make_engine):
+    """peers[i].Call("Raft.RequestVote" | "Raft.AppendEntries", args, reply) (labrpc.go:84-121) on the ends of one
+    config: the handler of the target peer runs (raft.go:200-232, 270-321), a disconnected end loses the request,
+    and the reply is decoded like gob does: zero fields do not overwrite (labgob.go:116-121)."""
+    from raft_amd.raft import AppendEntriesArgs, AppendEntriesReply, RequestVoteArgs, RequestVoteReply
+    eng = make_engine(n_groups=2, n_peers=3, log_cap=64, seed=5, apply_ring_cap=64)
+    cfg = Config(eng, 1, False)
+    leader = cfg.checkOneLeader()
+    assert leader == 0
+    ends = cfg.net.ends(2)                                  # server 2's ends
+    assert len(ends) == 3
+    # a vote request of a higher term: granted, and the leader it reaches is demoted (raft.go:208-216)
+    reply = RequestVoteReply(Term=0, VoteGranted=False)
+    assert ends[0].Call("Raft.RequestVote", RequestVoteArgs(5, 2, 0, 0), reply) is True
+    assert (reply.Term, reply.VoteGranted) == (5, True)
+    assert cfg.rafts[0].GetState() == (5, False)
+    # the same struct reused (raft.go:585-588): a refusal leaves VoteGranted as it was -- false is not transmitted
+    assert ends[1].Call("Raft.RequestVote", RequestVoteArgs(5, 1, 0, 0), reply) is True     # peer 1 has voted for 0 in term 1, no vote yet in 5
+    reply2 = RequestVoteReply(Term=5, VoteGranted=True)
+    assert ends[1].Call("Raft.RequestVote", RequestVoteArgs(5, 2, 0, 0), reply2) is True    # voted for 1 just now: refuses 2
+    assert reply2.VoteGranted is True
+    # a disconnected end: the request is lost, nothing is decoded
+    cfg.disconnect(1)
+    lost = RequestVoteReply(Term=-7, VoteGranted=False)
+    assert ends[1].Call("Raft.RequestVote", RequestVoteArgs(9, 2, 0, 0), lost) is False
+    assert (lost.Term, lost.VoteGranted) == (-7, False)
+    assert cfg.rafts[1].GetState()[0] == 5
+    cfg.connect(1)
+    # AppendEntries with arbitrary commands: appended, committed, applied as the objects they were
+    ar = AppendEntriesReply()
+    ok = ends[0].Call("Raft.AppendEntries", AppendEntriesArgs(6, 2, 0, 0, [(6, "x"), (6, ("y", 2))], 2), ar)
+    assert ok and (ar.Term, ar.Success) == (6, True)
+    assert eng.read("loglen")[1, 0] == 3 and eng.read("commit")[1, 0] == 2 and eng.read("vote")[1, 0] == 2
+    cfg.advance(2)
+    assert cfg.logs[0] == {1: "x", 2: ("y", 2)}
+    # a conflict hint (raft.go:303-314): PrevLogIndex past the end
+    ar = AppendEntriesReply()
+    assert ends[1].Call("Raft.AppendEntries", AppendEntriesArgs(6, 2, 7, 6, [], 0), ar)
+    assert (ar.Success, ar.ConflictTerm, ar.ConflictFirstIndex) == (False, -1, 1)
+    assert ends[1].Call("Raft.Nope", None, None) is False
+    return eng
+
+
+EXTRA = {"TwoConfigsOneEngine": two_configs_on_one_engine, "LabrpcEnds": labrpc_ends_reach_the_handlers}

@@ -25,6 +25,20 @@ def test_scenario(mk, name):
     scenarios.ALL[name](mk)
 
 
+@pytest.mark.parametrize("name", sorted(scenarios.EXTRA))
+def test_binding_model_matches_the_checker(name):
+    """Several configs on one engine and the labrpc-shaped ends: same asserts, and the same end state as the checker."""
+    import numpy as np
+    from oracle.binding import OracleEngine
+    from raft_amd import Engine
+    from tests.parity import diff_states
+    o = scenarios.EXTRA[name](lambda **kw: OracleEngine(_abi.make_config(**kw)))
+    e = scenarios.EXTRA[name](lambda **kw: Engine(_abi.make_config(**kw)))
+    assert o.now() == e.now()
+    assert not diff_states(o, e)
+    assert np.array_equal(o.state_hash(), e.state_hash())
+
+
 def test_reelection_split_vote_never_resolves(mk):
     with pytest.raises(TestFailure, match="expected one leader, got none"):
         scenarios.reelection_2a(mk)

@@ -40,3 +40,8 @@ def test_figure8_unreliable(mk, seed):
         scenarios.figure8_unreliable_2c(mk, seed=seed)
     except TestFailure as ex:
         assert "commit index=" in str(ex) or "committed values do not match" in str(ex)
+
+
+@pytest.mark.parametrize("name", sorted(scenarios.EXTRA))
+def test_binding_model(mk, name):
+    scenarios.EXTRA[name](mk)
