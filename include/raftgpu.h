@@ -115,6 +115,7 @@ enum {
   RG_F_LOGTERM = 48, RG_F_SNAPLOGTERM,  /* int32 [G][P][L]                   */
   RG_F_LOGCMD = 56, RG_F_SNAPLOGCMD,    /* uint64 [G][P][L]                  */
   RG_F_STARTSEQ = 64, RG_F_PARTNEXT, RG_F_PARTEPOCH, RG_F_RECMAX, RG_F_GFLAGS, /* int32 [G] */
+  RG_F_SCHEDPOS, RG_F_SCHEDREGS,     /* int32 [G]: next op of the schedule, the group's four peer registers (4 bits each, 15 = none) */
   RG_F_APPLYREC = 72,                /* uint64 [G][L]                        */
   /* read-only, int32 [G][P]: the engine's cached copies of log words (term of the last entry, first index from
    * which every entry carries currentTerm, term of the entry at commitIndex), for consistency checks */
@@ -241,6 +242,34 @@ int rg_set_unreliable_group(rg_engine *e, int32_t group, int32_t req_drop_permil
  * apply channels (ApplyMsgs of the old peers that were not drained are dropped).  Other groups are not touched;
  * counters keep counting. */
 int rg_reset_groups(rg_engine *e, const int32_t *groups, int64_t n);
+
+/* ---- scenario schedules: the tester's verbs for ALL groups at once ---------------------------------------------
+ * A schedule is a list of ops sorted by tick; at the start of tick `tick` (before the rolling partitions, the churn
+ * and the client Starts of that tick) every group of the engine executes the op on its own peers, inside the tick
+ * kernel: a scenario of test_test.go (connect / disconnect / crash1 / start1 / Start / checkOneLeader,
+ * config.go:99-278, 302-332, 430-477) runs on every group in one launch.  Peers are named by a selector: 0..7 an
+ * index, RG_SEL_ALL every peer, RG_SEL_REG(r, k) = (register r + k) mod n_peers, where the four registers of a
+ * group are set by the PICK ops (an op on an empty register does nothing).  Commands are hash(group, 1, b). */
+#define RG_SEL_ALL 0x80
+#define RG_SEL_REG(r, k) (0x100 | ((r) << 4) | (k))
+enum {
+  RG_OP_CONNECT = 1,       /* a: selector                                   config.go:235-256 */
+  RG_OP_DISCONNECT,        /* a: selector                                   config.go:258-278 */
+  RG_OP_CRASH,             /* a: selector; crash1                            config.go:99-127  */
+  RG_OP_RESTART,           /* a: selector; start1 (stays disconnected)       config.go:136-215 */
+  RG_OP_START,             /* a: selector, b: command number; rf.Start       raft.go:344-364   */
+  RG_OP_START_ANY,         /* b: command number; the first connected peer, in index order, that accepts  config.go:436-451 */
+  RG_OP_START_ALL,         /* a: register, b: command number; every live peer is asked, the register gets the last one that accepted  test_test.go:697-703 */
+  RG_OP_PICK_LEADER,       /* a: register := the connected leader of the highest term (lowest index), or none  config.go:302-332 */
+  RG_OP_PICK_RANDOM,       /* a: register := hash(group, op number, b) mod n_peers */
+  RG_OP_PICK_OTHER,        /* a: register := the first connected live peer after selector b, in cyclic order, or none */
+  RG_OP_RESTART_IF_FEWER,  /* a: selector, b: n; if that peer is dead and fewer than n peers are alive: start1 + connect  test_test.go:718-725 */
+  RG_OP_END
+};
+typedef struct rg_sched_op { int32_t tick, op, a, b; } rg_sched_op;
+/* Replaces the engine's schedule (n = 0: none).  Ops with tick < now are never executed.  Engines with a schedule
+ * run plain launches. */
+int rg_set_schedule(rg_engine *e, const rg_sched_op *ops, int64_t n);
 
 /* applyCh (raft.go:672-688): copies the ApplyMsgs the (group, peer) slot emitted since the last drain into buf,
  * in the order and with the commands of the moment they were emitted (raft.go:680-684): an entry applied and later

@@ -44,6 +44,7 @@ def load(path=None):
         "ro_set_unreliable": ([vp, i32, i32, i32], C.c_int),
         "ro_set_unreliable_group": ([vp, i32, i32, i32, i32], C.c_int),
         "ro_reset_groups": ([vp, P(i32), i64], C.c_int),
+        "ro_set_schedule": ([vp, P(_abi.SchedOp), i64], C.c_int),
         "ro_rpc_request_vote": ([vp, i32, i32, P(VoteArgs), P(VoteReply)], C.c_int),
         "ro_rpc_append_entries": ([vp, i32, i32, P(AppendArgs), P(i32), P(C.c_uint64), P(AppendReply)], C.c_int),
         "ro_read_state": ([vp, i32, vp, i64], C.c_int), "ro_write_state": ([vp, i32, vp, i64], C.c_int),

@@ -69,6 +69,7 @@ typedef struct {
   int32_t startSeq, partNext, partEpoch, recMax;
   uint32_t flags;
   int32_t netOwn, reqDrop, replyDrop, replyDelay;   /* the group's own net rates (config.go:288-294), when netOwn */
+  int32_t schedPos, schedRegs;                      /* scenario schedule: next op, four peer registers (4 bits each, 15 = none) */
   uint64_t *applyRec;    /* first command applied at each index, config.go:177-185 */
 } group_t;
 
@@ -77,6 +78,7 @@ struct ro_engine {
   int P, L, G;
   int64_t now;
   int fullPersist;
+  rg_sched_op *sched; int schedN;
   group_t *groups;
   uint64_t counters[RG_N_COUNTERS];
 };
@@ -90,6 +92,7 @@ typedef struct { uint64_t c[RG_N_COUNTERS]; } ctr_t;
 #define STREAM_CMD      3ull
 #define STREAM_PART     4ull
 #define STREAM_CHURN    5ull
+#define STREAM_SCHED    6ull
 
 static inline uint64_t sm64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -522,10 +525,90 @@ static void start1(ro_engine *e, ctr_t *c, group_t *g, int p, int32_t now) {
   make_peer(e, c, g, p, now);
 }
 
+/* ---------------- scenario schedule: the tester's verbs, one op ----------- */
+static int sched_resolve(const ro_engine *e, const group_t *g, int sel) {   /* -1 nobody, -2 everybody */
+  if (sel & 0x100) {
+    int base = (g->schedRegs >> (4 * ((sel >> 4) & 3))) & 15;
+    return base == 15 ? -1 : (base + (sel & 15)) % e->P;
+  }
+  return sel == RG_SEL_ALL ? -2 : sel;
+}
+static void sched_set_reg(group_t *g, int r, int val) {
+  int sh = 4 * (r & 3);
+  g->schedRegs = (g->schedRegs & ~(15 << sh)) | (val << sh);
+}
+static void sched_op(ro_engine *e, ctr_t *c, group_t *g, const rg_sched_op *op, int pos, int32_t tick) {
+  const int P = e->P;
+  const int tgt = sched_resolve(e, g, op->a);
+  int32_t idx, term, ok;
+  switch (op->op) {
+  case RG_OP_CONNECT:    for (int p = 0; p < P; p++) if (tgt == p || tgt == -2) g->peer[p].connected = 1; break;   /* config.go:235-256 */
+  case RG_OP_DISCONNECT: for (int p = 0; p < P; p++) if (tgt == p || tgt == -2) g->peer[p].connected = 0; break;   /* config.go:258-278 */
+  case RG_OP_CRASH:      for (int p = 0; p < P; p++) if (tgt == p || tgt == -2) crash1(g, p); break;
+  case RG_OP_RESTART:    for (int p = 0; p < P; p++) if (tgt == p || tgt == -2) start1(e, c, g, p, tick * RG_TICK_MS); break;
+  case RG_OP_RESTART_IF_FEWER: {                                            /* test_test.go:718-725 */
+    int alive = 0;
+    for (int p = 0; p < P; p++) alive += !g->peer[p].dead;
+    for (int p = 0; p < P; p++)
+      if ((tgt == p || tgt == -2) && g->peer[p].dead && alive < op->b) { start1(e, c, g, p, tick * RG_TICK_MS); g->peer[p].connected = 1; }
+    break;
+  }
+  case RG_OP_START:                                                         /* rf.Start on one peer */
+    if (tgt >= 0 && !g->peer[tgt].dead) start_cmd(e, c, g, tgt, stream_hash(g->key, STREAM_CMD, 1, (uint32_t)op->b), &idx, &term, &ok);
+    break;
+  case RG_OP_START_ANY:                                                     /* config.go:436-451 */
+    for (int p = 0; p < P; p++) {
+      peer_t *rf = &g->peer[p];
+      if (rf->dead || !rf->connected || !is_leader(rf)) continue;
+      start_cmd(e, c, g, p, stream_hash(g->key, STREAM_CMD, 1, (uint32_t)op->b), &idx, &term, &ok);
+      if (ok) break;
+    }
+    break;
+  case RG_OP_START_ALL: {                                                   /* test_test.go:697-703 */
+    int last = 15;
+    for (int p = 0; p < P; p++) {
+      if (g->peer[p].dead) continue;
+      start_cmd(e, c, g, p, stream_hash(g->key, STREAM_CMD, 1, (uint32_t)op->b), &idx, &term, &ok);
+      if (ok) last = p;
+    }
+    sched_set_reg(g, op->a, last);
+    break;
+  }
+  case RG_OP_PICK_LEADER: {                                                 /* config.go:302-332 */
+    int best = 15; int32_t bt = -1;
+    for (int p = 0; p < P; p++) {
+      const peer_t *rf = &g->peer[p];
+      if (rf->connected && is_leader(rf) && rf->term > bt) { bt = rf->term; best = p; }
+    }
+    sched_set_reg(g, op->a, best);
+    break;
+  }
+  case RG_OP_PICK_RANDOM:
+    sched_set_reg(g, op->a, (int)((uint32_t)(stream_hash(g->key, STREAM_SCHED, (uint32_t)pos, (uint32_t)op->b) >> 32) % (uint32_t)P));
+    break;
+  case RG_OP_PICK_OTHER: {
+    int base = sched_resolve(e, g, op->b), val = 15;
+    int from = base < 0 ? 0 : base + 1;
+    for (int q = 0; q < P && val == 15; q++) {
+      int p = (from + q) % P;
+      if (p != base && g->peer[p].connected && !g->peer[p].dead) val = p;
+    }
+    sched_set_reg(g, op->a, val);
+    break;
+  }
+  default: break;
+  }
+}
+
 /* ---------------- control phase ----------------------------------------- */
 static void control_step(ro_engine *e, ctr_t *c, group_t *g, int32_t now /* tick */) {
   const rg_config *cf = &e->cfg;
   const int P = e->P;
+  /* the scenario schedule, before anything else of the tick */
+  while (g->schedPos < e->schedN && e->sched[g->schedPos].tick <= now) {
+    sched_op(e, c, g, &e->sched[g->schedPos], g->schedPos, now);
+    g->schedPos++;
+  }
   /* rolling partitions, kvraft/test_test.go:124-143 + kvraft/config.go:174-186 */
   if (cf->part_period > 0 && now == g->partNext) {
     uint64_t h = stream_hash(g->key, STREAM_PART, (uint32_t)g->partEpoch, 0);
@@ -614,6 +697,8 @@ static void init_group(ro_engine *e, group_t *g, int64_t ggid, int32_t nowTick) 
   g->key = group_key(e->cfg.seed, ggid);
   g->startSeq = 0; g->partEpoch = 0; g->recMax = 0; g->flags = 0;
   g->netOwn = 0; g->reqDrop = g->replyDrop = g->replyDelay = 0;
+  g->schedRegs = 0xFFFF;
+  if (nowTick == 0) g->schedPos = 0;
   g->partNext = e->cfg.part_period > 0 ? nowTick + e->cfg.part_period : 0;
   memset(g->applyRec, 0, sizeof(uint64_t) * (size_t)e->L);
   for (int p = 0; p < e->P; p++) {
@@ -681,6 +766,7 @@ void ro_destroy(ro_engine *e) {
     }
   }
   free(e->groups);
+  free(e->sched);
   free(e);
 }
 
@@ -758,6 +844,23 @@ int ro_restart(ro_engine *e, int32_t g, int32_t p) {
   ctr_t c; memset(&c, 0, sizeof c);
   start1(e, &c, &e->groups[g], p, (int32_t)e->now * RG_TICK_MS);
   add_counters(e, &c);
+  return RG_OK;
+}
+int ro_set_schedule(ro_engine *e, const rg_sched_op *ops, int64_t n) {
+  if (!e || n < 0 || (n > 0 && !ops)) return RG_ERR_ARG;
+  for (int64_t i = 0; i < n; i++)
+    if (ops[i].op < RG_OP_CONNECT || ops[i].op >= RG_OP_END || ops[i].tick < 0 || (i > 0 && ops[i].tick < ops[i - 1].tick)) return RG_ERR_ARG;
+  free(e->sched);
+  e->sched = NULL; e->schedN = 0;
+  if (n > 0) {
+    e->sched = (rg_sched_op *)malloc(sizeof(rg_sched_op) * (size_t)n);
+    if (!e->sched) return RG_ERR_NOMEM;
+    memcpy(e->sched, ops, sizeof(rg_sched_op) * (size_t)n);
+    e->schedN = (int)n;
+  }
+  int first = 0;
+  while (first < n && ops[first].tick < e->now) first++;
+  for (int g = 0; g < e->G; g++) e->groups[g].schedPos = first;
   return RG_OK;
 }
 int ro_set_unreliable_group(ro_engine *e, int32_t g, int32_t a, int32_t b, int32_t d) {
@@ -847,6 +950,7 @@ static int32_t *group_i32(group_t *g, int field) {
   switch (field) {
   case RG_F_STARTSEQ: return &g->startSeq; case RG_F_PARTNEXT: return &g->partNext; case RG_F_PARTEPOCH: return &g->partEpoch;
   case RG_F_RECMAX: return &g->recMax;     case RG_F_GFLAGS: return (int32_t *)&g->flags;
+  case RG_F_SCHEDPOS: return &g->schedPos; case RG_F_SCHEDREGS: return &g->schedRegs;
   default: return NULL;
   }
 }
@@ -859,7 +963,8 @@ static int64_t field_bytes(const ro_engine *e, int field) {
   case RG_F_NEXTINDEX: case RG_F_MATCHINDEX: return G * P * P * 4;
   case RG_F_LOGTERM: case RG_F_SNAPLOGTERM: return G * P * L * 4;
   case RG_F_LOGCMD: case RG_F_SNAPLOGCMD: return G * P * L * 8;
-  case RG_F_STARTSEQ: case RG_F_PARTNEXT: case RG_F_PARTEPOCH: case RG_F_RECMAX: case RG_F_GFLAGS: return G * 4;
+  case RG_F_STARTSEQ: case RG_F_PARTNEXT: case RG_F_PARTEPOCH: case RG_F_RECMAX: case RG_F_GFLAGS:
+  case RG_F_SCHEDPOS: case RG_F_SCHEDREGS: return G * 4;
   case RG_F_APPLYREC: return G * L * 8;
   default: return -1;
   }
@@ -872,7 +977,7 @@ static int rw_state(ro_engine *e, int32_t field, void *buf, int64_t bytes, int w
   const int G = e->G, P = e->P, L = e->L;
   for (int g = 0; g < G; g++) {
     group_t *gr = &e->groups[g];
-    if (field >= RG_F_STARTSEQ && field <= RG_F_GFLAGS) {
+    if (field >= RG_F_STARTSEQ && field <= RG_F_SCHEDREGS) {
       int32_t *w = group_i32(gr, field), *b = (int32_t *)buf + g;
       if (wr) *w = *b; else *b = *w;
       continue;

@@ -47,6 +47,7 @@ int ro_restart(ro_engine *e, int32_t g, int32_t p);
 int ro_set_unreliable(ro_engine *e, int32_t req_drop, int32_t reply_drop, int32_t reply_delay);
 int ro_set_unreliable_group(ro_engine *e, int32_t g, int32_t req_drop, int32_t reply_drop, int32_t reply_delay);
 int ro_reset_groups(ro_engine *e, const int32_t *groups, int64_t n);
+int ro_set_schedule(ro_engine *e, const rg_sched_op *ops, int64_t n);
 
 int ro_drain_applied(ro_engine *e, int32_t g, int32_t p, rg_apply_msg *buf, int64_t cap, int64_t *n_out);
 

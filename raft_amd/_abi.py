@@ -46,10 +46,19 @@ FIELDS.update({
     "logterm": (48, "l32"), "snaplogterm": (49, "l32"),
     "logcmd": (56, "l64"), "snaplogcmd": (57, "l64"),
     "startseq": (64, "g32"), "partnext": (65, "g32"), "partepoch": (66, "g32"),
-    "recmax": (67, "g32"), "gflags": (68, "g32"),
+    "recmax": (67, "g32"), "gflags": (68, "g32"), "schedpos": (69, "g32"), "schedregs": (70, "g32"),
     "applyrec": (72, "r64"),
 })
 START_ONE, START_ALL = 0, 1
+
+# scenario schedule ops and selectors
+(OP_CONNECT, OP_DISCONNECT, OP_CRASH, OP_RESTART, OP_START, OP_START_ANY, OP_START_ALL, OP_PICK_LEADER, OP_PICK_RANDOM,
+ OP_PICK_OTHER, OP_RESTART_IF_FEWER) = range(1, 12)
+SEL_ALL = 0x80
+
+
+def SEL_REG(r, k=0):
+    return 0x100 | (r << 4) | k
 
 
 class Config(C.Structure):
@@ -89,6 +98,10 @@ class ApplyMsgC(C.Structure):
     _fields_ = [("command_index", C.c_int64), ("command", C.c_uint64)]
 
 
+class SchedOp(C.Structure):
+    _fields_ = [("tick", C.c_int32), ("op", C.c_int32), ("a", C.c_int32), ("b", C.c_int32)]
+
+
 class StartReq(C.Structure):
     _fields_ = [("group", C.c_int32), ("peer", C.c_int32), ("command", C.c_uint64),
                 ("index", C.c_int32), ("term", C.c_int32), ("is_leader", C.c_int32), ("pad", C.c_int32)]
@@ -109,7 +122,7 @@ def make_config(**kw):
 EXPORTS = [
     "rg_device_count", "rg_version", "rg_strerror", "rg_create", "rg_destroy", "rg_reset", "rg_set_stream",
     "rg_step", "rg_step_noalloc", "rg_sync", "rg_now", "rg_step_time_ms", "rg_start", "rg_start_batch", "rg_get_state",
-    "rg_set_connected", "rg_set_side", "rg_crash", "rg_restart", "rg_set_unreliable", "rg_set_unreliable_group", "rg_reset_groups", "rg_drain_applied",
+    "rg_set_connected", "rg_set_side", "rg_crash", "rg_restart", "rg_set_unreliable", "rg_set_unreliable_group", "rg_reset_groups", "rg_set_schedule", "rg_drain_applied",
     "rg_snapshot_export", "rg_snapshot_import", "rg_rpc_request_vote", "rg_rpc_append_entries",
     "rg_read_state", "rg_write_state", "rg_state_hash", "rg_counters", "rg_rpc_bytes", "rg_safety_check", "rg_safety_flags",
     "rg_device_buffers",
@@ -152,6 +165,7 @@ def load_library(path=None):
         "rg_set_unreliable": ([vp, i32, i32, i32], C.c_int),
         "rg_set_unreliable_group": ([vp, i32, i32, i32, i32], C.c_int),
         "rg_reset_groups": ([vp, P(i32), i64], C.c_int),
+        "rg_set_schedule": ([vp, P(SchedOp), i64], C.c_int),
         "rg_drain_applied": ([vp, i32, i32, P(ApplyMsgC), i64, P(i64)], C.c_int),
         "rg_snapshot_export": ([vp, i32, i32, vp, i64, P(i64)], C.c_int),
         "rg_snapshot_import": ([vp, i32, i32, vp, i64], C.c_int),

@@ -86,6 +86,8 @@ struct rg_engine {
   std::vector<unsigned> drained;  // per (g,p): ApplyMsgs handed out by rg_drain_applied so far
   rg_apply_msg *applyRing; unsigned *applyHead; int applyCap;
   unsigned *netCfg;               // device: per-group net rates, allocated by the first rg_set_unreliable_group
+  rg_sched_op *sched; int schedN; // device: the scenario schedule
+  std::vector<rg_sched_op> schedHost;
   std::mutex mu;
   // staging
   HostCmd *dCmd; size_t dCmdCap;
@@ -203,6 +205,7 @@ static int init_state(rg_engine *e) {
   HIPCHK(hipMemsetAsync(S.flagSummary, 0, 8, st));
   if (e->applyCap > 0) HIPCHK(hipMemsetAsync(e->applyHead, 0, (size_t)e->nLanes * sizeof(unsigned), st));
   if (e->netCfg) HIPCHK(hipMemsetAsync(e->netCfg, 0, (size_t)e->Gpad * sizeof(unsigned), st));
+  HIPCHK(hipMemsetAsync(S.schedPos, 0, (size_t)e->Gpad * sizeof(int), st));      // tick 0: the schedule starts over
   HIPCHK(hipStreamSynchronize(st));
   e->now = 0; e->derivedDirty = false; e->syncDirty = false;
   std::fill(e->drained.begin(), e->drained.end(), 0);
@@ -271,12 +274,14 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (rc == RG_OK) rc = dalloc(e, &S.partNext, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.partEpoch, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.recMax, (size_t)e->Gpad);
+  if (rc == RG_OK) rc = dalloc(e, &S.schedPos, (size_t)e->Gpad);
+  if (rc == RG_OK) rc = dalloc(e, &S.schedRegs, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.gflags, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.counters, (size_t)RG_CTR_SLOTS);
   if (rc == RG_OK) rc = dalloc(e, &S.flagSummary, (size_t)2);
   if (rc != RG_OK) { free_engine(e); return rc; }
   e->drained.assign((size_t)e->G * e->P, 0);
-  e->applyCap = cfg->apply_ring_cap; e->applyRing = nullptr; e->applyHead = nullptr; e->netCfg = nullptr;
+  e->applyCap = cfg->apply_ring_cap; e->applyRing = nullptr; e->applyHead = nullptr; e->netCfg = nullptr; e->sched = nullptr; e->schedN = 0;
   if (e->applyCap > 0) {
     rc = dalloc(e, &e->applyRing, (size_t)e->G * e->P * e->applyCap);
     if (rc == RG_OK) rc = dalloc(e, &e->applyHead, (size_t)e->nLanes);
@@ -289,7 +294,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
     if (rc != RG_OK) { free_engine(e); return rc; }
   }
   e->H.relay = e->relay; e->H.relayStage = e->relayStage;
-  e->H.applyRing = e->applyRing; e->H.applyHead = e->applyHead; e->H.applyCap = e->applyCap; e->H.netCfg = nullptr;
+  e->H.applyRing = e->applyRing; e->H.applyHead = e->applyHead; e->H.applyCap = e->applyCap; e->H.netCfg = nullptr; e->H.sched = nullptr; e->H.schedN = 0;
   e->H.logRows = S.logRows; e->H.snapRows = S.snapRows; e->H.nextIdx = S.nextIdx; e->H.matchIdx = S.matchIdx; e->H.applyRec = S.applyRec;
   if (dalloc(e, &e->dS, 1) != RG_OK || hipMemcpy(e->dS, &e->S, sizeof(DevPtrs), hipMemcpyHostToDevice) != hipSuccess) { free_engine(e); return RG_ERR_NOMEM; }
   rc = init_state(e);
@@ -359,7 +364,7 @@ static int run_derive(rg_engine *e) {
 #define RG_RELAY_MIN_TICKS 1000
 #define RG_RELAY_MAX_CHUNKS 12
 static int relay_chunk_ticks(const rg_engine *e, int n_ticks) {
-  if (e->relaySets == 0) return 0;
+  if (e->relaySets == 0 || e->schedN > 0) return 0;   // the schedule's per-group words do not travel through the relay's staging area
   int k = n_ticks / RG_RELAY_MIN_TICKS;
   if (k > RG_RELAY_MAX_CHUNKS) k = RG_RELAY_MAX_CHUNKS;
   if (const char *ov = getenv("RAFTGPU_RELAY_CHUNKS")) k = atoi(ov);   // tuning aid; 0 or 1: plain launches
@@ -383,7 +388,7 @@ static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage)
   if (getenv("RAFTGPU_TRACE_LAUNCH")) fprintf(stderr, "raftgpu: k_tick ticks=%d blocks=%d relay_sets=%d relay_chunk=%d groups_per_wave=%d\n", n_ticks, blocks, dc.relaySets, dc.relayChunk, dc.gwA);
   const DevPtrs *dS = e->dS;
 #define TICK_LAUNCH(PEERS) do { \
-    if (dc.acctBytes || H.applyCap > 0 || H.netCfg) hipLaunchKernelGGL((k_tick<PEERS, true>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
+    if (dc.acctBytes || H.applyCap > 0 || H.netCfg || H.schedN > 0) hipLaunchKernelGGL((k_tick<PEERS, true>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
     else hipLaunchKernelGGL((k_tick<PEERS, false>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)
   switch (e->P) {
   case 2: TICK_LAUNCH(2); break;
@@ -607,6 +612,31 @@ extern "C" int rg_set_unreliable_group(rg_engine *e, int32_t g, int32_t a, int32
   }
   const unsigned w = 0x80000000u | (unsigned)a | ((unsigned)b << 10) | ((unsigned)d << 20);
   HIPCHK(hipMemcpyAsync(e->netCfg + g, &w, 4, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return RG_OK;
+}
+
+extern "C" int rg_set_schedule(rg_engine *e, const rg_sched_op *ops, int64_t n) {
+  LOCK(e);
+  if (n < 0 || n > (1 << 24) || (n > 0 && !ops)) return RG_ERR_ARG;
+  for (int64_t i = 0; i < n; i++) {
+    if (ops[i].op < RG_OP_CONNECT || ops[i].op >= RG_OP_END || ops[i].tick < 0 || (i > 0 && ops[i].tick < ops[i - 1].tick)) return RG_ERR_ARG;
+    const int a = ops[i].a;
+    const bool isReg = ops[i].op == RG_OP_START_ALL || (ops[i].op >= RG_OP_PICK_LEADER && ops[i].op <= RG_OP_PICK_OTHER);
+    if (isReg ? (a < 0 || a > 3) : !((a >= 0 && a < e->P) || a == RG_SEL_ALL || ((a & ~0x3F) == 0x100 && (a & 15) < e->P)) && ops[i].op != RG_OP_START_ANY) return RG_ERR_ARG;
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->H.sched = nullptr; e->H.schedN = 0; e->schedN = 0;
+  e->schedHost.assign(ops, ops + n);
+  int first = 0;                                   // ops before the current tick are never executed
+  while (first < n && ops[first].tick < e->now) first++;
+  if (n > 0) {
+    int rc = dalloc(e, &e->sched, (size_t)n);      // (an earlier schedule's buffer stays until rg_destroy)
+    if (rc != RG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(e->sched, ops, (size_t)n * sizeof(rg_sched_op), hipMemcpyHostToDevice, e->stream));
+    e->H.sched = e->sched; e->H.schedN = (int)n; e->schedN = (int)n;
+  }
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->S.schedPos, first, (size_t)e->Gpad, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return RG_OK;
 }
@@ -864,7 +894,8 @@ static int64_t field_bytes(const rg_engine *e, int field) {
   case RG_F_NEXTINDEX: case RG_F_MATCHINDEX: return G * P * P * 4;
   case RG_F_LOGTERM: case RG_F_SNAPLOGTERM: return G * P * L * 4;
   case RG_F_LOGCMD: case RG_F_SNAPLOGCMD: return G * P * L * 8;
-  case RG_F_STARTSEQ: case RG_F_PARTNEXT: case RG_F_PARTEPOCH: case RG_F_RECMAX: case RG_F_GFLAGS: return G * 4;
+  case RG_F_STARTSEQ: case RG_F_PARTNEXT: case RG_F_PARTEPOCH: case RG_F_RECMAX: case RG_F_GFLAGS:
+  case RG_F_SCHEDPOS: case RG_F_SCHEDREGS: return G * 4;
   case RG_F_APPLYREC: return G * L * 8;
   default: return -1;
   }
@@ -902,6 +933,7 @@ static int *group_word(rg_engine *e, int field) {
   switch (field) {
   case RG_F_STARTSEQ: return S.startSeq; case RG_F_PARTNEXT: return S.partNext; case RG_F_PARTEPOCH: return S.partEpoch;
   case RG_F_RECMAX: return S.recMax; case RG_F_GFLAGS: return (int *)S.gflags;
+  case RG_F_SCHEDPOS: return S.schedPos; case RG_F_SCHEDREGS: return S.schedRegs;
   default: return nullptr;
   }
 }
@@ -1014,7 +1046,7 @@ static int rw_state(rg_engine *e, int field, void *buf, int64_t bytes, bool wr) 
     if (wr) { e->derivedDirty = true; e->syncDirty = true; }
     return RG_OK;
   }
-  if (field >= RG_F_STARTSEQ && field <= RG_F_GFLAGS) {
+  if (field >= RG_F_STARTSEQ && field <= RG_F_SCHEDREGS) {
     int *dev = group_word(e, field);
     if (wr) return h2d(e, dev, buf, (size_t)G * 4);
     return d2h(e, buf, dev, (size_t)G * 4);

@@ -145,6 +145,7 @@ __device__ static inline void init_lane(const DevPtrs &S, const DevCfg &c, int P
   for (int q = 0; q < PP; q++) { S.nextIdx[gl * PP + q] = 0; S.matchIdx[gl * PP + q] = 0; }
   if (p == 0) {
     S.startSeq[g] = 0; S.partEpoch[g] = 0; S.recMax[g] = 0; S.gflags[g] = 0;
+    S.schedRegs[g] = 0xFFFF;                                   // four empty registers; the schedule's position is the engine's
     S.partNext[g] = g < c.G && c.partPeriod > 0 ? nowTick + c.partPeriod : 0;
   }
 }

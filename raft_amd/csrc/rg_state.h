@@ -15,6 +15,7 @@ struct DevPtrs {
   char *logRows, *snapRows;
   u64 *applyRec;                 // [G][L]
   int *startSeq, *partNext, *partEpoch, *recMax;   // [Gpad]
+  int *schedPos, *schedRegs;     // [Gpad] scenario schedule: next op, the group's peer registers
   unsigned *gflags;              // [Gpad]
   u64 *counters;                 // [RG_N_COUNTERS]
   unsigned *flagSummary;         // [2]
@@ -53,6 +54,7 @@ struct DevCfg {
 #define STREAM_CMD      3ull
 #define STREAM_PART     4ull
 #define STREAM_CHURN    5ull
+#define STREAM_SCHED    6ull
 
 __host__ __device__ static inline u64 sm64(u64 x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -169,6 +171,7 @@ struct HotPtrs {
   rg_apply_msg *applyRing;       // [G * P][applyCap]: the ApplyMsgs each peer emitted, in order, slot = message number % applyCap
   unsigned *applyHead;           // [Gpad * PP], indexed like the per-peer words: messages emitted so far
   int applyCap;                  // 0: no ring (nobody reads applyCh from the host)
+  const rg_sched_op *sched; int schedN;   // the scenario schedule (sorted by tick), or null / 0
   const unsigned *netCfg;        // [Gpad] per-group net rates (bit 31: set; 10 bits each: request drop, reply drop, reply delay), or null
 };
 

@@ -210,7 +210,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     if (H.netCfg) { const unsigned nw = H.netCfg[gq]; if (nw >> 31) net = unpack_rates(nw); }
   }
 
-  __shared__ int coldLds[CD_N + 9 + (EXT ? 2 : 0)][256];   // peer words, 5 group words, the checked-apply cursor, the lane's cache of one leader's nextIndex / matchIndex pair, per-lane byte sums
+  __shared__ int coldLds[CD_N + 9 + (EXT ? 4 : 0)][256];   // peer words, 5 group words, the checked-apply cursor, the lane's cache of one leader's nextIndex / matchIndex pair, per-lane byte sums
   __shared__ int churnNext[GPB];                              // per group: its next churn tick (written by all its lanes alike)
   // The last RING entries each peer wrote to its log, staged in LDS: a follower copies a leader's fresh entries,
   // and every peer applies its fresh entries, without a trip to HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
@@ -234,6 +234,9 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     if (valid && peer == 0) stOut[5 * GPBPAD + gLoc] = sent;
   }
   if constexpr (EXT) { coldLds[CD_N + 9][threadIdx.x] = 0; coldLds[CD_N + 10][threadIdx.x] = 0; }
+#define gSchedPos coldLds[CD_N + 11][threadIdx.x]
+#define gRegs coldLds[CD_N + 12][threadIdx.x]
+  if constexpr (EXT) { gSchedPos = H.schedN > 0 ? Sp->schedPos[gq] : 0; gRegs = H.schedN > 0 ? Sp->schedRegs[gq] : 0xFFFF; }
 #define gPartNext coldLds[CD_N + 3][threadIdx.x]
 #define gRecMax coldLds[CD_N + 4][threadIdx.x]
   gPartNext = stIn ? stIn[2 * GPBPAD + gLoc] : Sp->partNext[gq]; gRecMax = stIn ? stIn[3 * GPBPAD + gLoc] : Sp->recMax[gq];
@@ -331,6 +334,9 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     cand = G.gmin(cand);
     if (c.partPeriod > 0 && gPartNext < cand) cand = gPartNext;
     if (c.churnPeriod > 0 && gChurnNext < cand) cand = gChurnNext;
+    if constexpr (EXT) {
+      if (H.schedN > 0 && valid && gSchedPos < H.schedN) { const int st = H.sched[gSchedPos].tick; cand = st < cand ? st : cand; }
+    }
     if (c.startPeriod > 0 && wave_any(startOn && sTick < cand)) {
       // The Start comes before anything else.  It changes no clock but its taker's gate (which then stays the
       // backlog one however many Starts follow), so it is not an event of its own: the group next runs when the
@@ -456,7 +462,82 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     const bool churnNow = c.churnPeriod > 0 && run && t == gChurnNext;
     // a Start of a tick the group skipped precedes this tick's control events (otherwise one call below does both)
     // (groups without a control event in this tick run theirs up to this tick at the same time)
-    if ((c.partPeriod > 0 || c.churnPeriod > 0) && wave_any(partNow || churnNow)) client_starts(run, (partNow || churnNow) ? t - 1 : t);
+    bool schedNow = false;
+    if constexpr (EXT) schedNow = H.schedN > 0 && run && valid && gSchedPos < H.schedN && H.sched[gSchedPos].tick <= t;
+    if ((c.partPeriod > 0 || c.churnPeriod > 0 || EXT) && wave_any(partNow || churnNow || schedNow)) client_starts(run, (partNow || churnNow || schedNow) ? t - 1 : t);
+    if constexpr (EXT) {
+      // ---- 0. the scenario schedule: the tester's verbs, by every group on its own peers (config.go:99-278, 302-332, 430-477)
+      if (wave_any(schedNow)) {
+        storesPending = true;
+        verify_applied(schedNow);              // nothing unchecked is left in a log an op may rewrite or replay
+        bool due = schedNow;
+        while (wave_any(due)) {
+          const int pos = due ? gSchedPos : 0;
+          const rg_sched_op op = H.sched[pos];
+          const int kind = due ? op.op : 0;
+          int regs = gRegs;
+          auto resolve = [&](int sel) -> int {   // -1: nobody, -2: everybody
+            if (sel & 0x100) { const int base = (regs >> (4 * ((sel >> 4) & 3))) & 15; return base == 15 ? -1 : (base + (sel & 15)) % P; }
+            return sel == RG_SEL_ALL ? -2 : sel;
+          };
+          const int tgt = resolve(op.a);
+          const bool me = due && (tgt == peer || tgt == -2);
+          if (kind == RG_OP_CONNECT && me) r.flags |= F_CONNECTED;
+          if (kind == RG_OP_DISCONNECT && me) r.flags &= ~F_CONNECTED;
+          if (kind == RG_OP_CRASH && me) { r.flags &= ~F_CONNECTED; r.flags |= F_DEAD; }
+          const int alive = __popc(G.ballot(valid && !r.has(F_DEAD)));
+          const bool again = kind == RG_OP_RESTART_IF_FEWER && me && r.has(F_DEAD) && alive < op.b;
+          if ((kind == RG_OP_RESTART && me) || again) {                    // start1: crash1, then Make + readPersist
+            r.flags &= ~F_CONNECTED; r.flags |= F_DEAD;
+            make_peer(r, lg, sn, peer, L, key, now, w);
+            lVerified = 0;
+#pragma unroll
+            for (int q = 0; q < RING; q++) ringIdx[q][tid] = -1;
+            if (again) r.flags |= F_CONNECTED;
+          }
+          const bool isStart = kind == RG_OP_START || kind == RG_OP_START_ANY || kind == RG_OP_START_ALL;
+          int val = 15;
+          if (wave_any(isStart)) {
+            const bool ask = isStart && valid && !r.has(F_DEAD) &&
+                             (kind == RG_OP_START ? tgt == peer : kind == RG_OP_START_ANY ? r.has(F_CONNECTED) : true);
+            bool go = ask;
+            if (kind == RG_OP_START_ANY) {       // leaders with a full log refuse (and are flagged) until one accepts
+              const unsigned mRoom = G.ballot(ask && r.isLeader() && r.logLen < L);
+              const int wIdx = mRoom ? (__ffs((int)mRoom) - 1) : NONE;
+              go = ask && r.isLeader() && peer <= wIdx;
+            }
+            int at = -1;
+            if (go) {
+              const u64 cmd = stream_hash(key, STREAM_CMD, 1, (unsigned)op.b);
+              at = start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
+              if (at >= 0) RING_PUSH(at, r.term, cmd);
+            }
+            const unsigned accM = G.ballot(at >= 0);
+            val = accM ? 31 - __clz((int)accM) : 15;
+          }
+          if (wave_any(kind == RG_OP_PICK_LEADER)) {
+            const bool lead = kind == RG_OP_PICK_LEADER && valid && r.has(F_CONNECTED) && r.isLeader();
+            const int tmax = G.gmax(lead ? r.term : -1);
+            const unsigned m = G.ballot(lead && r.term == tmax);
+            if (kind == RG_OP_PICK_LEADER) val = m ? (__ffs((int)m) - 1) : 15;
+          }
+          if (kind == RG_OP_PICK_RANDOM) val = (int)((unsigned)(stream_hash(key, STREAM_SCHED, (unsigned)pos, (unsigned)op.b) >> 32) % (unsigned)P);
+          if (wave_any(kind == RG_OP_PICK_OTHER)) {
+            const int base = resolve(op.b);
+            const unsigned okm = G.ballot(kind == RG_OP_PICK_OTHER && valid && r.has(F_CONNECTED) && !r.has(F_DEAD) && peer != base);
+            const int from = base < 0 ? 0 : base + 1;
+            const unsigned hi = from < P ? (okm >> from) : 0u;
+            if (kind == RG_OP_PICK_OTHER) val = hi ? (from + __ffs((int)hi) - 1) : (okm ? (__ffs((int)okm) - 1) : 15);
+          }
+          if (kind == RG_OP_START_ALL || kind == RG_OP_PICK_LEADER || kind == RG_OP_PICK_RANDOM || kind == RG_OP_PICK_OTHER) {
+            const int sh = 4 * (op.a & 3);
+            gRegs = (regs & ~(15 << sh)) | (val << sh);
+          }
+          if (due) gSchedPos = pos + 1;
+          due = due && gSchedPos < H.schedN && H.sched[gSchedPos].tick <= t;
+        }
+      }
+    }
     if (partNow) {
       // one hash per reshuffle: bit p = side of peer p, the upper half scaled to the jitter
       const u64 h = stream_hash(key, STREAM_PART, (unsigned)gPartEpoch, 0);
@@ -1029,11 +1110,15 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 #undef SYNC_STORES
 #undef RING_PUSH
   const int startSeqOut = gStartSeq, partEpochOut = gPartEpoch, partNextOut = gPartNext, recMaxOut = gRecMax;
+  int schedPosOut = 0, regsOut = 0;
+  if constexpr (EXT) { schedPosOut = gSchedPos; regsOut = gRegs; }
   if (EXT && c.acctBytes) {
     if (coldLds[CD_N + 9][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 9][threadIdx.x]);
     if (coldLds[CD_N + 10][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 10][threadIdx.x]);
   }
 #undef gStartSeq
+#undef gSchedPos
+#undef gRegs
 #undef cOwner
 #undef cNext
 #undef cMatch
@@ -1053,6 +1138,9 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   if (stOut) {                               // rounds sent in this span: how busy the group is, for the next span's dealing
     const int sent = G.gsum(valid ? r.cd(CD_ROUNDSEQ) : 0);
     if (valid && peer == 0) stOut[6 * GPBPAD + gLoc] = sent - stOut[5 * GPBPAD + gLoc];
+  }
+  if constexpr (EXT) {
+    if (H.schedN > 0 && valid && peer == 0) { Sp->schedPos[g] = schedPosOut; Sp->schedRegs[g] = regsOut; }
   }
   if (valid && peer == 0) {
     Sp->startSeq[g] = startSeqOut; Sp->partNext[g] = partNextOut; Sp->partEpoch[g] = partEpochOut; Sp->recMax[g] = recMaxOut;

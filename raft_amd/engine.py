@@ -112,6 +112,13 @@ class EngineBase(object):
         a = (C.c_int32 * len(groups))(*[int(g) for g in groups])
         self._check(self._fn("reset_groups")(self._h, a, len(groups)), "reset_groups")
 
+    def set_schedule(self, ops):
+        """ops: [(tick, op, a, b), ...] sorted by tick: the tester's verbs for every group at once (rg_set_schedule)."""
+        arr = (_abi.SchedOp * max(1, len(ops)))()
+        for i, (t, op, a, b) in enumerate(ops):
+            arr[i].tick, arr[i].op, arr[i].a, arr[i].b = int(t), int(op), int(a), int(b)
+        self._check(self._fn("set_schedule")(self._h, arr, len(ops)), "set_schedule")
+
     def snapshot_export(self, g, p):
         n = C.c_int64()
         self._check(self._fn("snapshot_export")(self._h, g, p, None, 0, C.byref(n)), "snapshot_export")

@@ -1,0 +1,98 @@
+"""Scenario schedules on the CPU checker: the ops do what the tester's verbs do, and the scenarios end as the
+reference's tests expect, in every group of the engine."""
+import numpy as np
+import pytest
+
+from raft_amd import _abi
+from raft_amd._abi import (OP_CONNECT, OP_CRASH, OP_DISCONNECT, OP_PICK_LEADER, OP_PICK_OTHER, OP_PICK_RANDOM, OP_RESTART,
+                           OP_RESTART_IF_FEWER, OP_START, OP_START_ALL, OP_START_ANY, SEL_ALL, SEL_REG)
+from tests import schedules
+
+
+@pytest.fixture
+def mk(oracle_lib):
+    from oracle.binding import OracleEngine
+    return lambda **kw: OracleEngine(_abi.make_config(**kw))
+
+
+def regs(e, g=0):
+    w = int(e.read("schedregs")[g])
+    return [(w >> (4 * r)) & 15 for r in range(4)]
+
+
+def test_ops_one_by_one(mk):
+    """Hand-checked: 3 lossless peers, peer 0 leads term 1 from tick ~12 (raft.go:545)."""
+    e = mk(n_groups=2, n_peers=3, log_cap=32, seed=1)
+    e.set_schedule([
+        (40, OP_PICK_LEADER, 0, 0), (40, OP_START, SEL_REG(0, 0), 7), (40, OP_START, SEL_REG(0, 1), 8),   # peer 1 is no leader: refused
+        (60, OP_PICK_OTHER, 1, SEL_REG(0, 0)), (60, OP_DISCONNECT, SEL_REG(1, 0), 0),
+        (61, OP_START_ANY, 0, 9), (80, OP_CRASH, 2, 0), (81, OP_START_ALL, 2, 10),
+        (90, OP_RESTART_IF_FEWER, 2, 2), (91, OP_RESTART_IF_FEWER, 2, 3), (92, OP_CONNECT, SEL_ALL, 0),
+        (93, OP_PICK_RANDOM, 3, 5), (200, OP_RESTART, 1, 0),
+    ])
+    e.step(41)
+    assert regs(e) == [0, 15, 15, 15] and e.read("loglen")[0, 0] == 2 and e.read("loglen")[0].max() == 2   # one Start accepted
+    e.step(20)
+    assert regs(e)[1] == 1 and e.read("connected")[0].tolist() == [1, 0, 1]
+    e.step(21)                      # tick 81 done: peer 2 crashed, START_ALL reached the one leader
+    assert e.read("dead")[0].tolist() == [0, 0, 1] and regs(e)[2] == 0
+    assert e.read("loglen")[0, 0] == 4 and e.read("commit")[0, 0] == 2     # 7 and 9 committed with peer 2; with 1 cut off and 2 dead command 10 cannot
+    e.step(9)                       # tick 90 done: two are alive, not fewer than 2: no restart
+    assert e.read("dead")[0, 2] == 1
+    e.step(1)                       # tick 91: fewer than 3: start1 + connect
+    assert e.read("dead")[0, 2] == 0 and e.read("connected")[0, 2] == 1
+    e.step(60)
+    assert e.read("connected")[0].tolist() == [1, 1, 1] and regs(e)[3] in (0, 1, 2)
+    assert e.read("commit")[0].tolist() == [3, 3, 3]
+    assert int(e.read("schedpos")[0]) == 12
+    e.step(50)                      # tick 200: start1 of a live peer: crashed, remade from its persister, off the net
+    assert e.read("connected")[0, 1] == 0 and e.read("applied")[0, 1] <= 3 and e.read("commit")[0, 1] == 3
+    assert np.array_equal(e.read("term")[0], e.read("term")[1])            # both groups did the same
+
+
+def test_schedule_validation(mk):
+    from raft_amd.engine import RaftGpuError
+    e = mk(n_groups=1, n_peers=3, log_cap=16, seed=1)
+    for bad in ([(5, 99, 0, 0)], [(9, OP_CONNECT, 0, 0), (3, OP_CONNECT, 0, 0)], [(-1, OP_CONNECT, 0, 0)]):
+        with pytest.raises(RaftGpuError):
+            e.set_schedule(bad)
+    e.step(10)
+    e.set_schedule([(5, OP_CRASH, SEL_ALL, 0), (20, OP_DISCONNECT, 1, 0)])   # the first op is in the past: never run
+    e.step(20)
+    assert e.read("dead")[0].tolist() == [0, 0, 0] and e.read("connected")[0].tolist() == [1, 0, 1]
+    e.set_schedule([])
+    assert int(e.read("schedpos")[0]) == 0
+
+
+def test_backup_2b_on_every_group(mk):
+    ops, ticks = schedules.backup_2b()
+    G = 128
+    e = mk(n_groups=G, n_peers=5, log_cap=256, seed=21)
+    e.set_schedule(ops)
+    e.step_mt(ticks, 8)
+    c = e.counters()
+    assert c["ae_conflicts"] >= G                            # the divergent logs were backed over (raft.go:303-314, 493-505)
+    flagged = e.safety_check()[1]
+    assert flagged <= 0.1 * G                                # (the reference elects on commitIndex, raft.go:218-219: some groups lose entries)
+    commit, loglen, lc = e.read("commit"), e.read("loglen"), e.read("logcmd")
+    # 1 + 50 + 50 + 1 commands commit; the two batches of 50 that never had a majority are overwritten.  A group
+    # whose three-peer side splits its vote stays without a leader (a failed candidate retries the SAME term,
+    # raft.go:569-573, 660) and misses commands: most groups get through, not all.
+    done = (commit == 102).all(axis=1) & (e.read("gflags") == 0)
+    assert done.sum() >= 0.85 * G
+    assert (loglen[done] == 103).all()
+    assert all((lc[g, :, 1:103] == lc[g, :1, 1:103]).all() for g in np.nonzero(done)[0])
+
+
+def test_figure8_2c_on_every_group(mk):
+    ops, ticks = schedules.figure8_2c()
+    e = mk(n_groups=64, n_peers=5, log_cap=256, seed=22)
+    e.set_schedule(ops)
+    e.step_mt(ticks, 8)
+    assert (e.read("dead") == 0).all() and (e.read("connected") == 1).all()
+    commit, lc = e.read("commit"), e.read("logcmd")
+    # the last command went through on all five (test_test.go:737) -- in nearly every group: one that is left without a
+    # leader (split vote retried in the same term, raft.go:569-573, 660) does not get there within the schedule
+    agreed = [bool((commit[g] == commit[g, 0]).all() and commit[g, 0] >= 2 and
+                   len({int(lc[g, p, commit[g, p]]) for p in range(5)}) == 1) for g in range(64)]
+    assert sum(agreed) >= 0.9 * 64
