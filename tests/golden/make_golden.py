@@ -62,6 +62,13 @@ def main():
     with open(path, "w") as f:
         json.dump(golden, f, indent=1, sort_keys=True)
     print("wrote", path)
+    # the same cases for the Go lockstep driver (bindings/go/lockstep/lockstep_test.go), which runs them on the
+    # reference's own code where a Go toolchain exists
+    cases = [{"name": name, "config": {k: int(v) for k, v in kw.items()}, "stops": stops} for name, (kw, stops) in sorted(CASES.items())]
+    cpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lockstep_cases.json")
+    with open(cpath, "w") as f:
+        json.dump(cases, f, indent=1, sort_keys=True)
+    print("wrote", cpath)
 
 
 if __name__ == "__main__":
