@@ -722,11 +722,12 @@ extern "C" int rg_snapshot_export(rg_engine *e, int32_t g, int32_t p, void *buf,
   if (g < 0 || g >= e->G || p < 0 || p >= e->P) return RG_ERR_RANGE;
   const size_t gl = (size_t)g * e->PP + p;
   int flags = 0, hdr[3];
-  int rc = d2h(e, &flags, e->S.flags + gl, 4);
-  if (rc == RG_OK) rc = d2h(e, &hdr[0], e->S.snapTerm + gl, 4);
-  if (rc == RG_OK) rc = d2h(e, &hdr[1], e->S.snapVote + gl, 4);
-  if (rc == RG_OK) rc = d2h(e, &hdr[2], e->S.snapLen + gl, 4);
-  if (rc != RG_OK) return rc;
+  HIPCHK(hipMemcpyAsync(&flags, e->S.flags + gl, 4, hipMemcpyDeviceToHost, e->stream));     // four words, one wait
+  HIPCHK(hipMemcpyAsync(&hdr[0], e->S.snapTerm + gl, 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(&hdr[1], e->S.snapVote + gl, 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(&hdr[2], e->S.snapLen + gl, 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  int rc = RG_OK;
   const bool has = ((unsigned)flags & F_SNAPHAS) != 0;
   const int n = has ? hdr[2] : 0;
   const int64_t size = has ? 16 + 16 * (int64_t)n : 0;

@@ -1062,7 +1062,9 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
               const int lo = __builtin_amdgcn_readlane(applied, src), n = __builtin_amdgcn_readlane(nOwn, src);
               const unsigned hd = (unsigned)__builtin_amdgcn_readlane((int)head, src), dn = (unsigned)__builtin_amdgcn_readlane((int)dense, src);
               rg_apply_msg *const ring = H.applyRing + (size_t)dn * (size_t)H.applyCap;
-              for (int j = G.lane; j < n; j += 64) {
+              // (of a burst longer than the ring only the last applyCap messages stay: the earlier ones would land in the
+              // same slots, and lanes that write one slot do so in no particular order)
+              for (int j = (n > H.applyCap ? n - H.applyCap : 0) + G.lane; j < n; j += 64) {
                 const int i = lo + 1 + j, ic = i < L ? i : L - 1;
                 const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
                 rg_apply_msg m; m.command_index = i; m.command = cmd;

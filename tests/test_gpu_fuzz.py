@@ -30,7 +30,38 @@ def _random_config(rng):
         kw.update(churn_period=rng.choice([35, 70]), churn_disconnect_permille=200, churn_restart_permille=500, churn_crash_permille=200)
     if rng.random() < 0.3:
         kw["account_bytes"] = 1
+    if rng.random() < 0.4:
+        kw["apply_ring_cap"] = rng.choice([8, 64, 400])
     return kw
+
+
+def _random_ops(rng, peers, until):
+    """A scenario schedule: random verbs at random ticks, for every group alike."""
+    ops, t = [], rng.randrange(5, 60)
+    regs_set = set()
+    while t < until:
+        kind = rng.choice(["pick_leader", "pick_random", "pick_other", "connect", "disconnect", "crash", "restart", "start", "start_any",
+                           "start_all", "restart_if_fewer"])
+        sel = rng.choice([rng.randrange(peers), _abi.SEL_ALL] + [_abi.SEL_REG(r, rng.randrange(peers)) for r in regs_set])
+        r = rng.randrange(4)
+        if kind == "pick_leader":
+            ops.append((t, _abi.OP_PICK_LEADER, r, 0)); regs_set.add(r)
+        elif kind == "pick_random":
+            ops.append((t, _abi.OP_PICK_RANDOM, r, rng.randrange(100))); regs_set.add(r)
+        elif kind == "pick_other":
+            ops.append((t, _abi.OP_PICK_OTHER, r, sel if sel != _abi.SEL_ALL else 0)); regs_set.add(r)
+        elif kind == "start_all":
+            ops.append((t, _abi.OP_START_ALL, r, rng.randrange(1 << 20))); regs_set.add(r)
+        elif kind == "start_any":
+            ops.append((t, _abi.OP_START_ANY, 0, rng.randrange(1 << 20)))
+        elif kind == "start":
+            ops.append((t, _abi.OP_START, sel, rng.randrange(1 << 20)))
+        elif kind == "restart_if_fewer":
+            ops.append((t, _abi.OP_RESTART_IF_FEWER, sel, rng.randrange(1, peers + 2)))
+        else:
+            ops.append((t, {"connect": _abi.OP_CONNECT, "disconnect": _abi.OP_DISCONNECT, "crash": _abi.OP_CRASH, "restart": _abi.OP_RESTART}[kind], sel, 0))
+        t += rng.choice([0, 0, 1, 3, 10, 40, 120])
+    return ops
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RAFT_FUZZ_SEEDS", "48"))))
@@ -40,6 +71,10 @@ def test_random_schedule(seed):
     rng = random.Random(1000 + seed)
     kw = _random_config(rng)
     o, e = OracleEngine(_abi.make_config(**kw)), Engine(_abi.make_config(**kw))
+    if rng.random() < 0.35:
+        ops = _random_ops(rng, kw["n_peers"], 1500)
+        o.set_schedule(ops)
+        e.set_schedule(ops)
     t = 0
     while t < 1500:
         n = rng.choice([1, 1, 2, 3, 5, 8, 13, 50, 200, 600])
@@ -50,7 +85,50 @@ def test_random_schedule(seed):
         assert not d, "config %r after tick %d: %s" % (kw, t, "; ".join(d[:5]))
         if rng.random() < 0.2:                      # host verbs between launches
             g, p = rng.randrange(kw["n_groups"]), rng.randrange(kw["n_peers"])
-            verb = rng.choice(["start", "disconnect", "connect", "crash", "restart"])
+            verb = rng.choice(["start", "disconnect", "connect", "crash", "restart", "move_blob", "vote", "append", "reset_group", "group_rates", "drain"])
+            if verb == "move_blob":                 # Persister swap: another peer's blob, then start1 from it (config.go:110-126, 159-163)
+                q = rng.randrange(kw["n_peers"])
+                blob = o.snapshot_export(g, q)
+                assert blob == e.snapshot_export(g, q)
+                for x in (o, e):
+                    x.snapshot_import(g, p, blob)
+                    x.restart(g, p)
+                    x.set_connected(g, p, True)
+                continue
+            if verb == "vote":                      # the exported handlers between launches (raft.go:200, 270)
+                term = int(o.read("term")[g].max()) + rng.choice([-1, 0, 1])
+                a = (term, rng.randrange(kw["n_peers"]), rng.randrange(0, 6), rng.randrange(0, term + 2))
+                assert o.request_vote(g, p, *a) == e.request_vote(g, p, *a)
+                continue
+            if verb == "append":
+                term = int(o.read("term")[g].max()) + rng.choice([-1, 0, 1])
+                ln = int(o.read("loglen")[g, p])
+                prev = min(rng.randrange(0, ln + 1), kw["log_cap"] - 1)
+                prevt = int(o.read("logterm")[g, p, min(prev, kw["log_cap"] - 1)]) if rng.random() < 0.7 else term
+                k = rng.randrange(0, max(0, min(4, kw["log_cap"] - prev - 1)) + 1)
+                a = (term, rng.randrange(kw["n_peers"]), prev, prevt, [(term, 777 + i) for i in range(k)], rng.randrange(0, ln + 2))
+                assert o.append_entries(g, p, *a) == e.append_entries(g, p, *a)
+                continue
+            if verb == "reset_group":
+                o.reset_groups([g])
+                e.reset_groups([g])
+                continue
+            if verb == "group_rates":
+                rates = (rng.choice([0, 100, 300]), rng.choice([0, 100]), rng.choice([0, 667]))
+                o.set_unreliable_group(g, *rates)
+                e.set_unreliable_group(g, *rates)
+                continue
+            if verb == "drain":
+                if kw.get("apply_ring_cap"):
+                    from raft_amd.engine import RaftGpuError
+                    res = []
+                    for x in (o, e):
+                        try:
+                            res.append(("ok", x.drain_applied(g, p)))
+                        except RaftGpuError as err:
+                            res.append((err.status, err.partial))
+                    assert res[0] == res[1]
+                continue
             for x in (o, e):
                 if verb == "start":
                     x.start(g, p, 12345 + t)
