@@ -1170,7 +1170,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 // a staging area with whole lines per set instead (the host lays out relay launches so that no other array has
 // a line with two sets in it).
 template <int P, bool EXT>
-__global__ __launch_bounds__(256, RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
+// (the extended instantiation carries the schedule's and the apply ring's code and is not asked to fit 4 waves per SIMD)
+__global__ __launch_bounds__(256, EXT ? 2 : RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
   __shared__ WaveCtr sctr[4];
   __shared__ int sItem;
   const int lane = (int)(threadIdx.x & 63);
