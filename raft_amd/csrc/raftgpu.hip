@@ -387,9 +387,11 @@ static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage)
   }
   if (getenv("RAFTGPU_TRACE_LAUNCH")) fprintf(stderr, "raftgpu: k_tick ticks=%d blocks=%d relay_sets=%d relay_chunk=%d groups_per_wave=%d\n", n_ticks, blocks, dc.relaySets, dc.relayChunk, dc.gwA);
   const DevPtrs *dS = e->dS;
+  const bool lean = dc.churnPeriod == 0 && dc.startMode == RG_START_ONE;     // nothing the lean instantiation leaves out is in use
 #define TICK_LAUNCH(PEERS) do { \
-    if (dc.acctBytes || H.applyCap > 0 || H.netCfg || H.schedN > 0) hipLaunchKernelGGL((k_tick<PEERS, true>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
-    else hipLaunchKernelGGL((k_tick<PEERS, false>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)
+    if (dc.acctBytes || H.applyCap > 0 || H.netCfg || H.schedN > 0) hipLaunchKernelGGL((k_tick<PEERS, true, false>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
+    else if (lean) hipLaunchKernelGGL((k_tick<PEERS, false, true>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
+    else hipLaunchKernelGGL((k_tick<PEERS, false, false>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)
   switch (e->P) {
   case 2: TICK_LAUNCH(2); break;
   case 3: TICK_LAUNCH(3); break;

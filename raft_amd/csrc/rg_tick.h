@@ -143,9 +143,11 @@ __device__ static inline int turn_start(u64 key, int tick, int P) {
 #endif
 // Ticks [t0, t0 + nticks) of one block's worth of groups (`set`: what blockIdx.x is in a plain launch), by the
 // whole block.  EXT: the extended instantiation, with wire-byte accounting (rg_config.account_bytes) and the
-// apply ring (rg_config.apply_ring_cap) compiled in; the plain instantiation carries none of it.  w: the calling wave's counters of the launch.  stIn / stOut: the set's group words as the
+// apply ring (rg_config.apply_ring_cap) compiled in; the plain instantiation carries none of it.  LEAN: the
+// instantiation for engines without churn and with the first-leader Start mode (the benchmark's), with that code left out
+// (17 instead of 25 spilled registers).  w: the calling wave's counters of the launch.  stIn / stOut: the set's group words as the
 // previous span left them / for the next span, when spans of one launch run on different blocks (else null).
-template <int P, bool EXT>
+template <int P, bool EXT, bool LEAN>
 __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, const DevCfg &c, const int set, const int t0, const int nticks, WaveCtr *w,
                                           const int *stIn, int *stOut) {
   constexpr int PP = P <= 4 ? 4 : 8;        // stride of a group in the per-peer arrays and matrices in memory
@@ -271,7 +273,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     gNextStart = ns;
     // the group's next churn tick: the first positive multiple of the period in this span or after it (never skipped)
     // (only the group's own lanes write its word: idle lanes carry gLoc 0, another wave's group)
-    if (valid) gChurnNext = c.churnPeriod > 0 ? ((t0 > 1 ? t0 : 1) + c.churnPeriod - 1) / c.churnPeriod * c.churnPeriod : 0x7fffffff;
+    if (valid) gChurnNext = (!LEAN && c.churnPeriod > 0) ? ((t0 > 1 ? t0 : 1) + c.churnPeriod - 1) / c.churnPeriod * c.churnPeriod : 0x7fffffff;
   }
   // wake-ups of this lane that lie before tick T and change nothing else
   auto catch_up = [&](int T) {
@@ -300,8 +302,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     const int sTick = gNextStart;
     const bool alive = valid && !r.has(F_DEAD);
     // who takes the pending Start: every leader with room (test_test.go:697-703) or the first connected one (config.go:436-451)
-    bool taker = startOn && alive && r.isLeader() && r.logLen < L && (c.startMode == RG_START_ALL || r.has(F_CONNECTED));
-    if (c.startPeriod > 0 && c.startMode != RG_START_ALL) {
+    bool taker = startOn && alive && r.isLeader() && r.logLen < L && ((!LEAN && c.startMode == RG_START_ALL) || r.has(F_CONNECTED));
+    if (c.startPeriod > 0 && !(!LEAN && c.startMode == RG_START_ALL)) {
       const unsigned tm = G.ballot(taker);
       taker = taker && peer == __ffs((int)tm) - 1;
     }
@@ -333,7 +335,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     }
     cand = G.gmin(cand);
     if (c.partPeriod > 0 && gPartNext < cand) cand = gPartNext;
-    if (c.churnPeriod > 0 && gChurnNext < cand) cand = gChurnNext;
+    if ((!LEAN && c.churnPeriod > 0) && gChurnNext < cand) cand = gChurnNext;
     if constexpr (EXT) {
       if (H.schedN > 0 && valid && gSchedPos < H.schedN) { const int st = H.sched[gSchedPos].tick; cand = st < cand ? st : cand; }
     }
@@ -393,7 +395,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
       const bool startNow = c.startPeriod > 0 && on && gNextStart <= upTo && gStartSeq < c.startMax;
       if (!(c.startPeriod > 0 && wave_any(startNow))) break;
       // client Starts: config.go:436-451 (first connected leader) / test_test.go:697-703 (every leader)
-      bool cand = startNow && valid && r.isLeader() && (c.startMode == RG_START_ALL || r.has(F_CONNECTED));
+      bool cand = startNow && valid && r.isLeader() && ((!LEAN && c.startMode == RG_START_ALL) || r.has(F_CONNECTED));
       const unsigned mAll = G.ballot(cand);
       if (startNow && mAll == 0) { do gNextStart += c.startPeriod; while (gNextStart <= upTo); }   // nobody to ask: these Starts change nothing
       if (wave_any(cand)) {
@@ -402,7 +404,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
         bool room = cand && r.logLen < L;
         const unsigned mRoom = G.ballot(room);
         unsigned below = (1u << peer) - 1u;
-        if (c.startMode == RG_START_ALL) {
+        if ((!LEAN && c.startMode == RG_START_ALL)) {
           if (startNow && mAll) gNextStart += c.startPeriod;
           int seq = gStartSeq + __popc(mRoom & below);
           bool tried = cand && seq < c.startMax;
@@ -459,12 +461,12 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     STAMP(9);
     // ------------------------------------------------------------ 1. control
     const bool partNow = c.partPeriod > 0 && run && t == gPartNext;
-    const bool churnNow = c.churnPeriod > 0 && run && t == gChurnNext;
+    const bool churnNow = (!LEAN && c.churnPeriod > 0) && run && t == gChurnNext;
     // a Start of a tick the group skipped precedes this tick's control events (otherwise one call below does both)
     // (groups without a control event in this tick run theirs up to this tick at the same time)
     bool schedNow = false;
     if constexpr (EXT) schedNow = H.schedN > 0 && run && valid && gSchedPos < H.schedN && H.sched[gSchedPos].tick <= t;
-    if ((c.partPeriod > 0 || c.churnPeriod > 0 || EXT) && wave_any(partNow || churnNow || schedNow)) client_starts(run, (partNow || churnNow || schedNow) ? t - 1 : t);
+    if ((c.partPeriod > 0 || (!LEAN && c.churnPeriod > 0) || EXT) && wave_any(partNow || churnNow || schedNow)) client_starts(run, (partNow || churnNow || schedNow) ? t - 1 : t);
     if constexpr (EXT) {
       // ---- 0. the scenario schedule: the tester's verbs, by every group on its own peers (config.go:99-278, 302-332, 430-477)
       if (wave_any(schedNow)) {
@@ -545,7 +547,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
       gPartNext = t + c.partPeriod + (int)(((u64)(unsigned)(h >> 32) * (u64)(unsigned)c.partJitter) >> 32);
       gPartEpoch++;
     }
-    if (c.churnPeriod > 0 && wave_any(churnNow)) { storesPending = true; verify_applied(churnNow && r.has(F_DEAD)); }   // a restart replays the log
+    if ((!LEAN && c.churnPeriod > 0) && wave_any(churnNow)) { storesPending = true; verify_applied(churnNow && r.has(F_DEAD)); }   // a restart replays the log
     if (churnNow) {                                                  // test_test.go:893-919
       gChurnNext = t + c.churnPeriod;
       unsigned it = (unsigned)(t / c.churnPeriod);
@@ -1169,7 +1171,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 // of its own to write back is not known to be refetched for its other bytes: the per-group words travel through
 // a staging area with whole lines per set instead (the host lays out relay launches so that no other array has
 // a line with two sets in it).
-template <int P, bool EXT>
+template <int P, bool EXT, bool LEAN>
 // (the extended instantiation carries the schedule's and the apply ring's code and is not asked to fit 4 waves per SIMD)
 __global__ __launch_bounds__(256, EXT ? 2 : RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
   __shared__ WaveCtr sctr[4];
@@ -1199,7 +1201,7 @@ __global__ __launch_bounds__(256, EXT ? 2 : RG_TICK_WAVES) void k_tick(const Dev
     }
   }
   __syncthreads();
-  tick_span<P, EXT>(Sp, H, c, set, t0, nticks, w, stIn, stOut);
+  tick_span<P, EXT, LEAN>(Sp, H, c, set, t0, nticks, w, stIn, stOut);
   if (c.relaySets > 0) {
     __syncthreads();                                 // every wave's stores have reached the L2; thread 0's release writes it back
     if (threadIdx.x == 0) {
