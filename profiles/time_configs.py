@@ -15,6 +15,8 @@ only = os.environ.get("ONLY")          # e.g. ONLY=cfg4
 for name, (kw, T) in CASES.items():
     if only and not name.startswith(only):
         continue
+    if os.environ.get("NGROUPS"):           # tuning aid: the same configuration with another number of groups
+        kw = dict(kw, n_groups=int(os.environ["NGROUPS"]))
     e = Engine(_abi.make_config(**kw))
     best, last = 1e30, 0.0
     for rep in range(2):
