@@ -116,6 +116,7 @@ type Group struct {
 	g         C.int32_t
 	n         int
 	cmds      map[uint64]interface{} // commands are opaque to the engine: it carries 64-bit handles
+	records   map[string][]byte      // gob raftstate this config wrote -> the engine record it was made from
 	next      uint64
 	rafts     []*Raft
 	connected []bool
@@ -135,7 +136,7 @@ func BeginConfig(n int, unreliable bool) *Group {
 	g := en.free[len(en.free)-1]
 	en.free = en.free[:len(en.free)-1]
 	status(C.rg_reset_groups(en.e, &g, 1), "rg_reset_groups")
-	grp := &Group{en: en, g: g, n: n, cmds: map[uint64]interface{}{}, next: 1,
+	grp := &Group{en: en, g: g, n: n, cmds: map[uint64]interface{}{}, records: map[string][]byte{}, next: 1,
 		rafts: make([]*Raft, n), connected: make([]bool, n)}
 	grp.setRates(unreliable, false)
 	grp.rpcs0, grp.bytes0 = grp.counters()
@@ -256,7 +257,11 @@ func (rf *Raft) SyncPersister() {
 	}
 	buf := make([]byte, int(size))
 	status(C.rg_snapshot_export(e, g, me, unsafe.Pointer(&buf[0]), size, &size), "rg_snapshot_export")
-	rf.ps.SaveRaftState(buf)
+	blob := rf.grp.gobFromRecord(buf) // the reference's own encoding (persist_gob.go)
+	rf.grp.mu.Lock()
+	rf.grp.records[string(blob)] = buf // a blob this config wrote comes back with its own command handles
+	rf.grp.mu.Unlock()
+	rf.ps.SaveRaftState(blob)
 }
 
 // Make, raft.go:700-731.  peers is kept for len(peers) only: the peers of a group talk inside the GPU.
@@ -270,11 +275,20 @@ func Make(peers []*labrpc.ClientEnd, me int, persister *Persister, applyCh chan 
 	grp.mu.Unlock()
 	blob := persister.ReadRaftState()
 	if !first || len(blob) > 0 {
-		var p unsafe.Pointer
-		if len(blob) > 0 {
-			p = unsafe.Pointer(&blob[0])
+		grp.mu.Lock()
+		rec, mine := grp.records[string(blob)]
+		grp.mu.Unlock()
+		if !mine && len(blob) > 0 { // written by other code, e.g. the reference's persist(): raft.go:116-122
+			var err error
+			if rec, err = grp.recordFromGob(blob); err != nil {
+				rec = nil // readPersist logs and starts empty (raft.go:141-142)
+			}
 		}
-		status(C.rg_snapshot_import(grp.en.e, grp.g, C.int32_t(me), p, C.int64_t(len(blob))), "rg_snapshot_import")
+		var p unsafe.Pointer
+		if len(rec) > 0 {
+			p = unsafe.Pointer(&rec[0])
+		}
+		status(C.rg_snapshot_import(grp.en.e, grp.g, C.int32_t(me), p, C.int64_t(len(rec))), "rg_snapshot_import")
 		status(C.rg_restart(grp.en.e, grp.g, C.int32_t(me)), "rg_restart")
 	}
 	grp.mu.Lock()
