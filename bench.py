@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--launch-ticks", type=int, default=0, help="ticks per kernel launch (0 = the whole schedule)")
     ap.add_argument("--cpu-groups", type=int, default=16384)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--generic", action="store_true",
+                    help="run the precompiled generic kernel instead of the one rg_specialize compiles for this configuration")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="run the N ranks on GPU 0 over gloo: checks the multi-rank path on a 1-GPU box; its line is marked and is no measurement")
     args = ap.parse_args()
@@ -166,6 +168,13 @@ def main():
     cfg.device = local
     eng = Engine(cfg)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    specialized = False
+    if not args.generic:
+        try:
+            eng.specialize()            # the tick kernel compiled for this configuration (about a second, before the warm-up)
+            specialized = True
+        except Exception as err:      # hiprtc missing: the generic kernel runs, and the line says so
+            sys.stderr.write("bench: rg_specialize failed (%s); running the generic kernel\n" % err)
     launch = args.launch_ticks or args.ticks
     from raft_amd.distributed import all_reduce_summary
 
@@ -236,11 +245,12 @@ def main():
                             args.part_period + 19, args.entries, args.ticks),
             "groups_total": world * args.groups, "peers": args.peers, "ticks_per_step": args.ticks,
             "ticks_per_launch": launch, "parallelism": "groups sharded x%d, no data-path collective" % world, "seed": args.seed,
+            "kernel_build": "compiled at engine set-up for this configuration (rg_specialize)" if specialized else "generic, precompiled",
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": "k_tick", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "kernel": "k_tick_spec" if specialized else "k_tick", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
             # the two parts of the algorithmic figure: the per-tick floor (40 B x peers x group-ticks), which a fused
             # launch never moves, and the bytes of the counted events; and the same rate against the measured peak
             "floor_bytes": floor_bytes, "event_bytes": event_bytes,

@@ -25,9 +25,9 @@ def tick_waves(G, slots=4096, gw_max=12):
 
 wt = tick_waves(G) * T
 names = ["client Starts", "classify", "(rest of actors)", "apply", "leader check", "pend header+election", "RV section", "monitor eval", "AE section",
-         "key + catch-up", "partitions, churn", "next event"]
+         "key + catch-up", "partitions, churn", "next event", "client Starts before a control event"]
 cnt = {"pend header+election": 0, "RV section": 1, "monitor eval": 2, "AE section": 3, "apply": 4}
-tot = sum(buf[40:52])
+tot = sum(buf[40:53])
 for i, n in enumerate(names):
     extra = ""
     if n in cnt and buf[_abi.N_COUNTERS + cnt[n]]:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel time of the other named configurations (one rank's share), for the numbers table.
-usage: python profiles/time_configs.py"""
+usage: python profiles/time_configs.py       (GENERIC=1: the precompiled kernel instead of the one rg_specialize builds)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raft_amd import Engine, _abi
@@ -18,6 +18,8 @@ for name, (kw, T) in CASES.items():
     if os.environ.get("NGROUPS"):           # tuning aid: the same configuration with another number of groups
         kw = dict(kw, n_groups=int(os.environ["NGROUPS"]))
     e = Engine(_abi.make_config(**kw))
+    if not os.environ.get("GENERIC"):
+        e.specialize()
     best, last = 1e30, 0.0
     for rep in range(2):
         e.reset(); e.step(T); e.sync()

@@ -121,7 +121,7 @@ def make_config(**kw):
 # every symbol include/raftgpu.h declares
 EXPORTS = [
     "rg_device_count", "rg_version", "rg_strerror", "rg_create", "rg_destroy", "rg_reset", "rg_set_stream",
-    "rg_step", "rg_step_noalloc", "rg_sync", "rg_now", "rg_step_time_ms", "rg_start", "rg_start_batch", "rg_get_state",
+    "rg_step", "rg_step_noalloc", "rg_specialize", "rg_sync", "rg_now", "rg_step_time_ms", "rg_start", "rg_start_batch", "rg_get_state",
     "rg_set_connected", "rg_set_side", "rg_crash", "rg_restart", "rg_set_unreliable", "rg_set_unreliable_group", "rg_reset_groups", "rg_set_schedule", "rg_drain_applied",
     "rg_snapshot_export", "rg_snapshot_import", "rg_rpc_request_vote", "rg_rpc_append_entries",
     "rg_read_state", "rg_write_state", "rg_state_hash", "rg_counters", "rg_rpc_bytes", "rg_safety_check", "rg_safety_flags",
@@ -152,6 +152,7 @@ def load_library(path=None):
         "rg_set_stream": ([vp, vp], C.c_int),
         "rg_step": ([vp, i32], C.c_int),
         "rg_step_noalloc": ([vp, i32], C.c_int),
+        "rg_specialize": ([vp], C.c_int),
         "rg_sync": ([vp], C.c_int),
         "rg_now": ([vp, P(i64)], C.c_int),
         "rg_step_time_ms": ([vp, P(C.c_double), P(i64)], C.c_int),

@@ -19,6 +19,8 @@
 // targets of a round evaluate their handler at once without touching state, the break point is found with a
 // ballot, and only targets up to it commit their effects: the result is the sequential one.
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdint>
@@ -27,6 +29,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -91,6 +94,10 @@ struct rg_engine {
   std::mutex mu;
   // staging
   HostCmd *dCmd; size_t dCmdCap;
+  // the tick kernel compiled for this engine's configuration (rg_specialize), and what it was compiled for
+  bool specWanted;
+  hipModule_t specMod; hipFunction_t specFn;
+  bool specExt, specLean; DevCfg specFor;
 };
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { return RG_ERR_HIP; } } while (0)
@@ -222,6 +229,7 @@ static void free_engine(rg_engine *e) {
   for (void *p : e->allocs) hipFree(p);
   if (e->dCmd) hipFree(e->dCmd);
   if (e->ownStream) hipStreamDestroy(e->ownStream);
+  if (e->specMod) hipModuleUnload(e->specMod);
   delete e;
 }
 
@@ -304,6 +312,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (dalloc(e, &e->dS, 1) != RG_OK || hipMemcpy(e->dS, &e->S, sizeof(DevPtrs), hipMemcpyHostToDevice) != hipSuccess) { free_engine(e); return RG_ERR_NOMEM; }
   rc = init_state(e);
   if (rc != RG_OK) { free_engine(e); return rc; }
+  { const char *v = getenv("RAFTGPU_SPECIALIZE"); e->specWanted = v && atoi(v) > 0; }   // as rg_specialize, compiled at the first launch
   *out = e;
   return RG_OK;
 }
@@ -377,8 +386,107 @@ static int relay_chunk_ticks(const rg_engine *e, int n_ticks) {
   return (n_ticks + k - 1) / k;
 }
 
+// ---------------------------------------------------------------- a tick kernel compiled for one engine
+// rg_specialize: the device sources (this library's own, embedded below as they were when it was built) are compiled
+// again at run time through hiprtc with everything rg_create fixed as compile-time constants (RG_SPEC_* in
+// rg_tick.h).  hiprtc is loaded when first asked for, so the library does not depend on it otherwise.
+#if !defined(__HIP_DEVICE_COMPILE__)
+__asm__(".pushsection .rodata\n"
+        ".hidden rg_src_abi\n.global rg_src_abi\nrg_src_abi:\n.incbin \"raftgpu.h\"\n.byte 0\n"
+        ".hidden rg_src_state\n.global rg_src_state\nrg_src_state:\n.incbin \"rg_state.h\"\n.byte 0\n"
+        ".hidden rg_src_tick\n.global rg_src_tick\nrg_src_tick:\n.incbin \"rg_tick.h\"\n.byte 0\n"
+        ".popsection\n");
+#endif
+extern "C" const char rg_src_abi[], rg_src_state[], rg_src_tick[];
+static const char kSpecUnit[] =
+    "#include \"raftgpu.h\"\ntypedef unsigned long long u64;\n#include \"rg_state.h\"\n#include \"rg_tick.h\"\n";
+// what hiprtc's built-in headers leave to the standard ones raftgpu.h includes
+static const char kSpecStdint[] =
+    "#pragma once\ntypedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
+    "typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;\n";
+static const char kSpecStddef[] = "#pragma once\n";
+
+struct Rtc {
+  void *lib = nullptr;
+  decltype(&hiprtcCreateProgram) create = nullptr;
+  decltype(&hiprtcCompileProgram) compile = nullptr;
+  decltype(&hiprtcGetProgramLogSize) logSize = nullptr;
+  decltype(&hiprtcGetProgramLog) log = nullptr;
+  decltype(&hiprtcGetCodeSize) codeSize = nullptr;
+  decltype(&hiprtcGetCode) code = nullptr;
+  decltype(&hiprtcDestroyProgram) destroy = nullptr;
+};
+static const Rtc *rtc() {
+  static Rtc r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+#define RTC_SYM(field, sym) r.field = (decltype(r.field))dlsym(r.lib, #sym)
+    RTC_SYM(create, hiprtcCreateProgram); RTC_SYM(compile, hiprtcCompileProgram); RTC_SYM(logSize, hiprtcGetProgramLogSize);
+    RTC_SYM(log, hiprtcGetProgramLog); RTC_SYM(codeSize, hiprtcGetCodeSize); RTC_SYM(code, hiprtcGetCode); RTC_SYM(destroy, hiprtcDestroyProgram);
+#undef RTC_SYM
+    if (!(r.create && r.compile && r.logSize && r.log && r.codeSize && r.code && r.destroy)) r.lib = nullptr;
+  });
+  return r.lib ? &r : nullptr;
+}
+
+// the fields of DevCfg a specialised kernel has as constants
+static bool spec_same(const DevCfg &a, const DevCfg &b) {
+  return a.P == b.P && a.L == b.L && a.rowBytes == b.rowBytes && a.cmdOff == b.cmdOff && a.reqDrop == b.reqDrop && a.replyDrop == b.replyDrop &&
+         a.replyDelay == b.replyDelay && a.startPeriod == b.startPeriod && a.startFirst == b.startFirst && a.startMax == b.startMax &&
+         a.startMode == b.startMode && a.partPeriod == b.partPeriod && a.partJitter == b.partJitter && a.churnPeriod == b.churnPeriod &&
+         a.churnDisc == b.churnDisc && a.churnRestart == b.churnRestart && a.churnCrash == b.churnCrash && a.acctBytes == b.acctBytes;
+}
+
+// Compiles and loads k_tick_spec for the engine's configuration as it is now (device of the engine current).
+static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
+  const Rtc *r = rtc();
+  if (!r) return RG_ERR_STATE;
+  if (e->specMod) { hipModuleUnload(e->specMod); e->specMod = nullptr; e->specFn = nullptr; }
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, e->cfg.device));
+  std::string arch = prop.gcnArchName;                       // "gfx950:sramecc+:xnack-"
+  arch = "--offload-arch=" + arch.substr(0, arch.find(':'));
+  std::vector<std::string> opts = {arch, "-O3", "-std=c++17", "-Wno-unused-value"};
+  auto def = [&](const char *name, long long v) { opts.push_back(std::string("-DRG_SPEC_") + name + "=" + std::to_string(v)); };
+  def("P", c.P); def("EXT", ext); def("LEAN", lean); def("L", c.L); def("ROWBYTES", c.rowBytes); def("CMDOFF", c.cmdOff);
+  def("REQDROP", c.reqDrop); def("REPLYDROP", c.replyDrop); def("REPLYDELAY", c.replyDelay);
+  def("STARTPERIOD", c.startPeriod); def("STARTFIRST", c.startFirst); def("STARTMAX", c.startMax); def("STARTMODE", c.startMode);
+  def("PARTPERIOD", c.partPeriod); def("PARTJITTER", c.partJitter);
+  def("CHURNPERIOD", c.churnPeriod); def("CHURNDISC", c.churnDisc); def("CHURNRESTART", c.churnRestart); def("CHURNCRASH", c.churnCrash);
+  def("ACCTBYTES", c.acctBytes);
+  std::vector<const char *> optv;
+  for (auto &o : opts) optv.push_back(o.c_str());
+  const char *hdrs[] = {rg_src_abi, rg_src_state, rg_src_tick, kSpecStdint, kSpecStddef};
+  const char *names[] = {"raftgpu.h", "rg_state.h", "rg_tick.h", "stdint.h", "stddef.h"};
+  hiprtcProgram prog;
+  if (r->create(&prog, kSpecUnit, "raftgpu_spec.hip", 5, hdrs, names) != HIPRTC_SUCCESS) return RG_ERR_HIP;
+  const hiprtcResult res = r->compile(prog, (int)optv.size(), optv.data());
+  if (res != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    if (r->logSize(prog, &n) == HIPRTC_SUCCESS && n > 1) { std::string log(n, 0); r->log(prog, &log[0]); fprintf(stderr, "raftgpu: rg_specialize: hiprtc: %s\n", log.c_str()); }
+    r->destroy(&prog);
+    return RG_ERR_HIP;
+  }
+  size_t n = 0;
+  std::vector<char> code;
+  if (r->codeSize(prog, &n) == HIPRTC_SUCCESS && n > 0) { code.resize(n); if (r->code(prog, code.data()) != HIPRTC_SUCCESS) code.clear(); }
+  r->destroy(&prog);
+  if (code.empty()) return RG_ERR_HIP;
+  HIPCHK(hipModuleLoadData(&e->specMod, code.data()));
+  if (hipModuleGetFunction(&e->specFn, e->specMod, "k_tick_spec") != hipSuccess) { hipModuleUnload(e->specMod); e->specMod = nullptr; e->specFn = nullptr; return RG_ERR_HIP; }
+  e->specExt = ext; e->specLean = lean; e->specFor = c;
+  return RG_OK;
+}
+
 // One launch of the tick kernel.  relay / relayStage: the queue and staging area a relay launch uses.
-static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage) {
+// mayCompile: a specialised kernel that no longer fits the configuration may be rebuilt here (never on the path that
+// must not allocate).
+static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage, bool mayCompile) {
   DevCfg dc = e->dc;
   HotPtrs H = e->H;
   H.relay = relay; H.relayStage = relayStage;
@@ -393,8 +501,19 @@ static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage)
   if (getenv("RAFTGPU_TRACE_LAUNCH")) fprintf(stderr, "raftgpu: k_tick ticks=%d blocks=%d relay_sets=%d relay_chunk=%d groups_per_wave=%d\n", n_ticks, blocks, dc.relaySets, dc.relayChunk, dc.gwA);
   const DevPtrs *dS = e->dS;
   const bool lean = dc.churnPeriod == 0 && dc.startMode == RG_START_ONE;     // nothing the lean instantiation leaves out is in use
+  const bool ext = dc.acctBytes || H.applyCap > 0 || H.netCfg || H.schedN > 0;
+  if (e->specWanted) {
+    const bool fits = e->specFn && e->specExt == ext && e->specLean == (lean && !ext) && spec_same(e->specFor, dc);
+    if (!fits && mayCompile && build_spec(e, ext, lean && !ext, dc) != RG_OK) e->specWanted = false;   // said once by build_spec; the generic kernel serves
+    if (e->specFn && e->specExt == ext && e->specLean == (lean && !ext) && spec_same(e->specFor, dc)) {
+      int t0 = (int)e->now, n = n_ticks;
+      void *params[] = {(void *)&dS, (void *)&H, (void *)&dc, (void *)&t0, (void *)&n};
+      HIPCHK(hipModuleLaunchKernel(e->specFn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, e->stream, params, nullptr));
+      return RG_OK;
+    }
+  }
 #define TICK_LAUNCH(PEERS) do { \
-    if (dc.acctBytes || H.applyCap > 0 || H.netCfg || H.schedN > 0) hipLaunchKernelGGL((k_tick<PEERS, true, false>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
+    if (ext) hipLaunchKernelGGL((k_tick<PEERS, true, false>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
     else if (lean) hipLaunchKernelGGL((k_tick<PEERS, false, true>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
     else hipLaunchKernelGGL((k_tick<PEERS, false, false>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)
   switch (e->P) {
@@ -418,13 +537,22 @@ static int launch_ticks(rg_engine *e, int n_ticks) {
   // the pair is owned by pendingEv from here on (collect_events and free_engine destroy it), whatever happens below
   e->pendingEv.push_back(std::make_pair(a, b));
   HIPCHK(hipEventRecord(a, e->stream));
-  int rc = launch_kernel(e, n_ticks, e->relay, e->relayStage);
+  int rc = launch_kernel(e, n_ticks, e->relay, e->relayStage, true);
   if (rc != RG_OK) return rc;
   HIPCHK(hipEventRecord(b, e->stream));
   e->launches++;
   e->now += n_ticks;
   // group-ticks are counted on the host side of the counter block
   return RG_OK;
+}
+
+extern "C" int rg_specialize(rg_engine *e) {
+  LOCK(e);
+  const bool lean = e->dc.churnPeriod == 0 && e->dc.startMode == RG_START_ONE;
+  const bool ext = e->dc.acctBytes || e->H.applyCap > 0 || e->H.netCfg || e->H.schedN > 0;
+  int rc = build_spec(e, ext, lean && !ext, e->dc);
+  if (rc == RG_OK) e->specWanted = true;
+  return rc;
 }
 
 extern "C" int rg_step(rg_engine *e, int32_t n_ticks) {
@@ -462,7 +590,7 @@ extern "C" int rg_step_noalloc(rg_engine *e, int32_t n_ticks) {
   int *const queue = e->scratchDev, *const stage = e->scratchDev + relay_queue_ints(e);
   while (n_ticks > 0) {
     const int n = n_ticks < RG_MAX_LAUNCH_TICKS ? n_ticks : RG_MAX_LAUNCH_TICKS;
-    rc = launch_kernel(e, n, queue, stage);      // clears the queue words it uses; the staging area is written before it is read
+    rc = launch_kernel(e, n, queue, stage, false);      // clears the queue words it uses; the staging area is written before it is read
     if (rc != RG_OK) return rc;
     e->now += n;
     n_ticks -= n;

@@ -427,11 +427,40 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           if (wIdx == NONE) take = 0;
           if (startNow && mAll && wIdx < NONE && take < due) gNextStart -= (due - take) * c.startPeriod;   // the rest goes round again
           if (cand && peer < wIdx) (void)start_cmd(r, lg, sn, peer, L, 0, gfl, w);            // full log: refused and flagged
-          if (cand && peer == wIdx) {
-            for (int j = 0; j < take; j++) {
-              u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)(gStartSeq + j));
-              const int at = start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
-              if (at >= 0) RING_PUSH(at, r.term, cmd);
+          const bool lead = cand && peer == wIdx && take > 0;
+          if (wave_any(lead && r.commit >= r.logLen)) {        // a commitIndex that ran past the log: entry by entry
+            if (lead) {
+              for (int j = 0; j < take; j++) {
+                u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)(gStartSeq + j));
+                const int at = start_cmd(r, lg, sn, peer, L, cmd, gfl, w);
+                if (at >= 0) RING_PUSH(at, r.term, cmd);
+              }
+            }
+          } else {
+            // The group's lanes share the entries out: each works out its commands and writes them into the leader's
+            // column (and the last RING of them into the leader's ring); the leader then does the bookkeeping of
+            // `take` Start()s at once.  With commitIndex below the first new entry, persist() after the first
+            // Start has nothing new to count, and no entry is the one at commitIndex.
+            const int wSafe = wIdx < NONE ? wIdx : 0;
+            const int idx0 = G.shfl(r.logLen, wSafe), termW = G.shfl(r.term, wSafe);
+            const bool help = startNow && mAll != 0 && valid && take > 0;
+            const int lt = tid - peer + wSafe;
+            for (int j = peer; wave_any(help && j < take); j += P) {
+              if (help && j < take) {
+                const u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)(gStartSeq + j));
+                const int at = idx0 + j;
+                *lg.termp(at, wSafe) = termW;
+                *lg.cmdp(at, wSafe) = cmd;
+                if (take - j <= RING) { const int q = at & (RING - 1); ringIdx[q][lt] = at; ringTerm[q][lt] = termW; ringCmd[q][lt] = cmd; }
+              }
+            }
+            if (lead) {
+              if (idx0 < r.cd(CD_SNAPSYNC)) r.cd(CD_SNAPSYNC) = idx0;
+              r.logLen = idx0 + take;
+              r.cd(CD_LASTTERM) = r.term;
+              persist(r, L, w);
+              if (take > 1) ctr_add(w, RG_C_PERSISTS, (unsigned)(take - 1));
+              ctr_add(w, RG_C_ENTRIES_STARTED, (unsigned)take);
             }
           }
           if (startNow && mAll) gStartSeq += take;
@@ -467,6 +496,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     bool schedNow = false;
     if constexpr (EXT) schedNow = H.schedN > 0 && run && valid && gSchedPos < H.schedN && H.sched[gSchedPos].tick <= t;
     if ((c.partPeriod > 0 || (!LEAN && c.churnPeriod > 0) || EXT) && wave_any(partNow || churnNow || schedNow)) client_starts(run, (partNow || churnNow || schedNow) ? t - 1 : t);
+    STAMP(12);
     if constexpr (EXT) {
       // ---- 0. the scenario schedule: the tester's verbs, by every group on its own peers (config.go:99-278, 302-332, 430-477)
       if (wave_any(schedNow)) {
@@ -1172,8 +1202,18 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 // a staging area with whole lines per set instead (the host lays out relay launches so that no other array has
 // a line with two sets in it).
 template <int P, bool EXT, bool LEAN>
-// (the extended instantiation carries the schedule's and the apply ring's code and is not asked to fit 4 waves per SIMD)
-__global__ __launch_bounds__(256, EXT ? 2 : RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
+__device__ __forceinline__ void tick_launch(const DevPtrs *Sp, HotPtrs &H, DevCfg &c, int t0, int nticks) {
+#ifdef RG_SPEC_P
+  // A build for one engine's configuration (rg_specialize compiles this file at run time): what rg_create fixed is a
+  // compile-time constant here, so it costs no scalar register and folds into the arithmetic around it.
+  c.P = RG_SPEC_P; c.L = RG_SPEC_L; c.rowBytes = RG_SPEC_ROWBYTES; c.cmdOff = RG_SPEC_CMDOFF;
+  c.reqDrop = RG_SPEC_REQDROP; c.replyDrop = RG_SPEC_REPLYDROP; c.replyDelay = RG_SPEC_REPLYDELAY;
+  c.startPeriod = RG_SPEC_STARTPERIOD; c.startFirst = RG_SPEC_STARTFIRST; c.startMax = RG_SPEC_STARTMAX; c.startMode = RG_SPEC_STARTMODE;
+  c.partPeriod = RG_SPEC_PARTPERIOD; c.partJitter = RG_SPEC_PARTJITTER;
+  c.churnPeriod = RG_SPEC_CHURNPERIOD; c.churnDisc = RG_SPEC_CHURNDISC; c.churnRestart = RG_SPEC_CHURNRESTART; c.churnCrash = RG_SPEC_CHURNCRASH;
+  c.acctBytes = RG_SPEC_ACCTBYTES;
+#endif
+
   __shared__ WaveCtr sctr[4];
   __shared__ int sItem;
   const int lane = (int)(threadIdx.x & 63);
@@ -1212,5 +1252,17 @@ __global__ __launch_bounds__(256, EXT ? 2 : RG_TICK_WAVES) void k_tick(const Dev
   __syncthreads();
   if (lane < RG_WAVE_CTR_SLOTS && w->c[lane]) atomicAdd((unsigned long long *)&Sp->counters[lane], (unsigned long long)w->c[lane]);
 }
+
+// (the extended instantiation carries the schedule's and the apply ring's code and is not asked to fit 4 waves per SIMD)
+#ifdef RG_SPEC_P
+extern "C" __global__ __launch_bounds__(256, RG_SPEC_EXT ? 2 : RG_TICK_WAVES) void k_tick_spec(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
+  tick_launch<RG_SPEC_P, RG_SPEC_EXT != 0, RG_SPEC_LEAN != 0>(Sp, H, c, t0, nticks);
+}
+#else
+template <int P, bool EXT, bool LEAN>
+__global__ __launch_bounds__(256, EXT ? 2 : RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
+  tick_launch<P, EXT, LEAN>(Sp, H, c, t0, nticks);
+}
+#endif
 
 #endif
