@@ -459,6 +459,14 @@ static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
   def("PARTPERIOD", c.partPeriod); def("PARTJITTER", c.partJitter);
   def("CHURNPERIOD", c.churnPeriod); def("CHURNDISC", c.churnDisc); def("CHURNRESTART", c.churnRestart); def("CHURNCRASH", c.churnCrash);
   def("ACCTBYTES", c.acctBytes);
+  // code objects already compiled in this process, by option string: engines of one configuration share the compile
+  static std::mutex cacheMu;
+  static std::unordered_map<std::string, std::vector<char>> cache;
+  std::string key;
+  for (auto &o : opts) { key += o; key += ' '; }
+  std::vector<char> code;
+  { std::lock_guard<std::mutex> lk(cacheMu); auto it = cache.find(key); if (it != cache.end()) code = it->second; }
+  if (code.empty()) {
   std::vector<const char *> optv;
   for (auto &o : opts) optv.push_back(o.c_str());
   const char *hdrs[] = {rg_src_abi, rg_src_state, rg_src_tick, kSpecStdint, kSpecStddef};
@@ -473,10 +481,13 @@ static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
     return RG_ERR_HIP;
   }
   size_t n = 0;
-  std::vector<char> code;
   if (r->codeSize(prog, &n) == HIPRTC_SUCCESS && n > 0) { code.resize(n); if (r->code(prog, code.data()) != HIPRTC_SUCCESS) code.clear(); }
   r->destroy(&prog);
   if (code.empty()) return RG_ERR_HIP;
+  std::lock_guard<std::mutex> lk(cacheMu);
+  if (cache.size() >= 256) cache.clear();
+  cache[key] = code;
+  }
   HIPCHK(hipModuleLoadData(&e->specMod, code.data()));
   if (hipModuleGetFunction(&e->specFn, e->specMod, "k_tick_spec") != hipSuccess) { hipModuleUnload(e->specMod); e->specMod = nullptr; e->specFn = nullptr; return RG_ERR_HIP; }
   e->specExt = ext; e->specLean = lean; e->specFor = c;
