@@ -93,7 +93,8 @@ struct rg_engine {
   std::vector<rg_sched_op> schedHost;
   std::mutex mu;
   // staging
-  HostCmd *dCmd; size_t dCmdCap;
+  HostCmd *dCmd, *hCmd; size_t dCmdCap;     // device and pinned host staging of host commands
+  std::vector<unsigned> cmdStamp; std::vector<int> cmdSeen; unsigned cmdEpoch;   // per group: batch that last named it, and how often so far
   // the tick kernel compiled for this engine's configuration (rg_specialize), and what it was compiled for
   bool specWanted;
   hipModule_t specMod; hipFunction_t specFn;
@@ -228,6 +229,7 @@ static void free_engine(rg_engine *e) {
   for (auto &pr : e->pendingEv) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   for (void *p : e->allocs) hipFree(p);
   if (e->dCmd) hipFree(e->dCmd);
+  if (e->hCmd) hipHostFree(e->hCmd);
   if (e->ownStream) hipStreamDestroy(e->ownStream);
   if (e->specMod) hipModuleUnload(e->specMod);
   delete e;
@@ -268,7 +270,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   e->nLanes = (long long)e->Gpad * e->PP;
   e->cmdOff = (e->P * 4 + 7) & ~7;
   e->rowBytes = (e->cmdOff + e->P * 8 + 15) & ~15;
-  e->ownStream = nullptr; e->dCmd = nullptr; e->dCmdCap = 0; e->stepMs = 0; e->launches = 0;
+  e->ownStream = nullptr; e->dCmd = nullptr; e->hCmd = nullptr; e->dCmdCap = 0; e->cmdEpoch = 0; e->stepMs = 0; e->launches = 0;
   if (hipStreamCreateWithFlags(&e->ownStream, hipStreamNonBlocking) != hipSuccess) { delete e; return RG_ERR_HIP; }
   e->stream = e->ownStream;
   DevPtrs &S = e->S;
@@ -634,33 +636,48 @@ extern "C" int rg_step_time_ms(rg_engine *e, double *total_ms, int64_t *launches
 
 static int ensure_cmd_buf(rg_engine *e, size_t n) {
   if (n <= e->dCmdCap) return RG_OK;
-  if (e->dCmd) { hipFree(e->dCmd); e->dCmd = nullptr; e->dCmdCap = 0; }
+  if (e->dCmd) { hipFree(e->dCmd); e->dCmd = nullptr; }
+  if (e->hCmd) { hipHostFree(e->hCmd); e->hCmd = nullptr; }
+  e->dCmdCap = 0;
   size_t cap = std::max<size_t>(n, 1024);
   if (hipMalloc((void **)&e->dCmd, cap * sizeof(HostCmd)) != hipSuccess) return RG_ERR_NOMEM;
+  if (hipHostMalloc((void **)&e->hCmd, cap * sizeof(HostCmd), hipHostMallocDefault) != hipSuccess) { hipFree(e->dCmd); e->dCmd = nullptr; return RG_ERR_NOMEM; }
   e->dCmdCap = cap;
   return RG_OK;
 }
 
-// Runs host commands in order.  Commands on one group are kept in order by
-// cutting the batch into launches in which every group appears at most once.
-static int run_cmds(rg_engine *e, std::vector<HostCmd> &cmds) {
-  const size_t n = cmds.size();
+// Runs the n host commands the caller has written into e->hCmd (pinned; ensure_cmd_buf(e, n) first), in order, and
+// leaves their results there.  Commands on one group are kept in order by cutting the batch into launches in which
+// every group appears at most once; a batch that names every group once -- the common one -- is one launch, sent and
+// fetched in place.
+static int run_staged_cmds(rg_engine *e, size_t n) {
   if (n == 0) return RG_OK;
-  for (auto &cm : cmds) if (cm.group < 0 || cm.group >= e->G || cm.peer < 0 || cm.peer >= e->P) return RG_ERR_RANGE;
+  HostCmd *cmds = e->hCmd;
+  for (size_t i = 0; i < n; i++) if (cmds[i].group < 0 || cmds[i].group >= e->G || cmds[i].peer < 0 || cmds[i].peer >= e->P) return RG_ERR_RANGE;
   int rc = run_derive(e);
   if (rc != RG_OK) return rc;
-  std::vector<int> level(n, 0);
+  // level of a command = how many earlier commands of the batch name its group (stamped per batch: no clearing)
   int maxLevel = 0;
+  std::vector<int> level;
   if (n > 1) {
-    std::unordered_map<int, int> last;
+    if (e->cmdStamp.size() != (size_t)e->G) { e->cmdStamp.assign((size_t)e->G, 0u); e->cmdSeen.assign((size_t)e->G, 0); e->cmdEpoch = 0; }
+    if (++e->cmdEpoch == 0) { std::fill(e->cmdStamp.begin(), e->cmdStamp.end(), 0u); e->cmdEpoch = 1; }
     for (size_t i = 0; i < n; i++) {
-      auto it = last.find(cmds[i].group);
-      int lv = it == last.end() ? 0 : it->second + 1;
-      last[cmds[i].group] = lv; level[i] = lv; maxLevel = std::max(maxLevel, lv);
+      const int g = cmds[i].group;
+      int lv = 0;
+      if (e->cmdStamp[g] == e->cmdEpoch) lv = ++e->cmdSeen[g]; else { e->cmdStamp[g] = e->cmdEpoch; e->cmdSeen[g] = 0; }
+      if (lv > 0 && level.empty()) level.assign(n, 0);
+      if (lv > 0) { level[i] = lv; maxLevel = std::max(maxLevel, lv); }
     }
   }
-  rc = ensure_cmd_buf(e, n);
-  if (rc != RG_OK) return rc;
+  if (maxLevel == 0) {
+    HIPCHK(hipMemcpyAsync(e->dCmd, cmds, n * sizeof(HostCmd), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_host_cmds, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, e->stream, e->S, e->dc, e->PP, e->dCmd, (int)n, (int)e->now * RG_TICK_MS);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(cmds, e->dCmd, n * sizeof(HostCmd), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return RG_OK;
+  }
   std::vector<HostCmd> sorted; sorted.reserve(n);
   std::vector<size_t> src; src.reserve(n);
   std::vector<size_t> startOf(maxLevel + 2, 0);
@@ -683,11 +700,12 @@ static int run_cmds(rg_engine *e, std::vector<HostCmd> &cmds) {
 }
 
 static int run_one(rg_engine *e, int op, int g, int p, u64 arg, HostCmd *res) {
-  std::vector<HostCmd> v(1);
-  memset(&v[0], 0, sizeof(HostCmd));
-  v[0].op = op; v[0].group = g; v[0].peer = p; v[0].arg = arg;
-  int rc = run_cmds(e, v);
-  if (rc == RG_OK && res) *res = v[0];
+  int rc = ensure_cmd_buf(e, 1);
+  if (rc != RG_OK) return rc;
+  memset(&e->hCmd[0], 0, sizeof(HostCmd));
+  e->hCmd[0].op = op; e->hCmd[0].group = g; e->hCmd[0].peer = p; e->hCmd[0].arg = arg;
+  rc = run_staged_cmds(e, 1);
+  if (rc == RG_OK && res) *res = e->hCmd[0];
   return rc;
 }
 
@@ -705,9 +723,11 @@ extern "C" int rg_start(rg_engine *e, int32_t g, int32_t p, uint64_t cmd, int32_
 extern "C" int rg_start_batch(rg_engine *e, rg_start_req *reqs, int64_t n) {
   LOCK(e);
   if (n < 0 || (n > 0 && !reqs)) return RG_ERR_ARG;
-  std::vector<HostCmd> v((size_t)n);
-  for (int64_t i = 0; i < n; i++) { memset(&v[i], 0, sizeof(HostCmd)); v[i].op = OP_START; v[i].group = reqs[i].group; v[i].peer = reqs[i].peer; v[i].arg = reqs[i].command; }
-  int rc = run_cmds(e, v);
+  int rc = ensure_cmd_buf(e, (size_t)n);
+  if (rc != RG_OK) return rc;
+  HostCmd *v = e->hCmd;
+  for (int64_t i = 0; i < n; i++) { v[i].op = OP_START; v[i].group = reqs[i].group; v[i].peer = reqs[i].peer; v[i].pad = 0; v[i].arg = reqs[i].command; v[i].r0 = v[i].r1 = v[i].r2 = v[i].r3 = 0; }
+  rc = run_staged_cmds(e, (size_t)n);
   if (rc != RG_OK) return rc;
   for (int64_t i = 0; i < n; i++) { reqs[i].index = v[i].r0; reqs[i].term = v[i].r1; reqs[i].is_leader = v[i].r2; }
   return RG_OK;
