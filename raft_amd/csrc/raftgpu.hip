@@ -634,6 +634,22 @@ extern "C" int rg_step_time_ms(rg_engine *e, double *total_ms, int64_t *launches
   return RG_OK;
 }
 
+// Level of each of n requests = how many earlier requests of the batch name its group (groups[i * stride]); returns the
+// highest.  Per-group stamps of the batch instead of a map or a clear: O(n).
+static int batch_levels(rg_engine *e, const int32_t *groups, size_t stride, size_t n, std::vector<int> &level) {
+  level.assign(n, 0);
+  int maxLevel = 0;
+  if (n < 2) return 0;
+  if (e->cmdStamp.size() != (size_t)e->G) { e->cmdStamp.assign((size_t)e->G, 0u); e->cmdSeen.assign((size_t)e->G, 0); e->cmdEpoch = 0; }
+  if (++e->cmdEpoch == 0) { std::fill(e->cmdStamp.begin(), e->cmdStamp.end(), 0u); e->cmdEpoch = 1; }
+  for (size_t i = 0; i < n; i++) {
+    const int g = groups[i * stride];
+    if (e->cmdStamp[g] == e->cmdEpoch) { level[i] = ++e->cmdSeen[g]; maxLevel = std::max(maxLevel, level[i]); }
+    else { e->cmdStamp[g] = e->cmdEpoch; e->cmdSeen[g] = 0; }
+  }
+  return maxLevel;
+}
+
 static int ensure_cmd_buf(rg_engine *e, size_t n) {
   if (n <= e->dCmdCap) return RG_OK;
   if (e->dCmd) { hipFree(e->dCmd); e->dCmd = nullptr; }
@@ -656,20 +672,8 @@ static int run_staged_cmds(rg_engine *e, size_t n) {
   for (size_t i = 0; i < n; i++) if (cmds[i].group < 0 || cmds[i].group >= e->G || cmds[i].peer < 0 || cmds[i].peer >= e->P) return RG_ERR_RANGE;
   int rc = run_derive(e);
   if (rc != RG_OK) return rc;
-  // level of a command = how many earlier commands of the batch name its group (stamped per batch: no clearing)
-  int maxLevel = 0;
   std::vector<int> level;
-  if (n > 1) {
-    if (e->cmdStamp.size() != (size_t)e->G) { e->cmdStamp.assign((size_t)e->G, 0u); e->cmdSeen.assign((size_t)e->G, 0); e->cmdEpoch = 0; }
-    if (++e->cmdEpoch == 0) { std::fill(e->cmdStamp.begin(), e->cmdStamp.end(), 0u); e->cmdEpoch = 1; }
-    for (size_t i = 0; i < n; i++) {
-      const int g = cmds[i].group;
-      int lv = 0;
-      if (e->cmdStamp[g] == e->cmdEpoch) lv = ++e->cmdSeen[g]; else { e->cmdStamp[g] = e->cmdEpoch; e->cmdSeen[g] = 0; }
-      if (lv > 0 && level.empty()) level.assign(n, 0);
-      if (lv > 0) { level[i] = lv; maxLevel = std::max(maxLevel, lv); }
-    }
-  }
+  const int maxLevel = batch_levels(e, &cmds[0].group, sizeof(HostCmd) / sizeof(int32_t), n, level);
   if (maxLevel == 0) {
     HIPCHK(hipMemcpyAsync(e->dCmd, cmds, n * sizeof(HostCmd), hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_host_cmds, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, e->stream, e->S, e->dc, e->PP, e->dCmd, (int)n, (int)e->now * RG_TICK_MS);
@@ -963,21 +967,15 @@ extern "C" int rg_snapshot_import(rg_engine *e, int32_t g, int32_t p, const void
 
 // ---- batched RPC handlers --------------------------------------------------------
 // order[]: request indices sorted so that each launch level holds one request per group
-static void level_order(const int32_t *groups, int64_t n, std::vector<int> &order, std::vector<size_t> &startOf) {
-  std::vector<int> level((size_t)n, 0);
-  int maxLevel = 0;
-  std::unordered_map<int, int> last;
-  for (int64_t i = 0; i < n; i++) {
-    auto it = last.find(groups[i]);
-    int lv = it == last.end() ? 0 : it->second + 1;
-    last[groups[i]] = lv; level[i] = lv; maxLevel = std::max(maxLevel, lv);
-  }
-  order.clear(); startOf.assign(maxLevel + 2, 0);
-  for (int lv = 0; lv <= maxLevel; lv++) {
-    startOf[lv] = order.size();
-    for (int64_t i = 0; i < n; i++) if (level[i] == lv) order.push_back((int)i);
-  }
-  startOf[maxLevel + 1] = order.size();
+static void level_order(rg_engine *e, const int32_t *groups, int64_t n, std::vector<int> &order, std::vector<size_t> &startOf) {
+  std::vector<int> level;
+  const int maxLevel = batch_levels(e, groups, 1, (size_t)n, level);
+  startOf.assign(maxLevel + 2, 0);
+  for (int64_t i = 0; i < n; i++) startOf[level[i] + 1]++;
+  for (int lv = 0; lv <= maxLevel; lv++) startOf[lv + 1] += startOf[lv];
+  order.assign((size_t)n, 0);
+  std::vector<size_t> at(startOf.begin(), startOf.end() - 1);
+  for (int64_t i = 0; i < n; i++) order[at[level[i]]++] = (int)i;       // stable: requests of a level keep their order
 }
 
 extern "C" int rg_rpc_request_vote(rg_engine *e, int64_t n, const int32_t *groups, const int32_t *peers,
@@ -989,7 +987,7 @@ extern "C" int rg_rpc_request_vote(rg_engine *e, int64_t n, const int32_t *group
   int rc = run_derive(e);
   if (rc != RG_OK) return rc;
   std::vector<int> order; std::vector<size_t> startOf;
-  level_order(groups, n, order, startOf);
+  level_order(e, groups, n, order, startOf);
   TmpBuf tb;
   int *dg = tb.get<int>(n), *dp = tb.get<int>(n), *dord = tb.get<int>(n);
   rg_vote_args *da = tb.get<rg_vote_args>(n); rg_vote_reply *dr = tb.get<rg_vote_reply>(n);
@@ -1025,7 +1023,7 @@ extern "C" int rg_rpc_append_entries(rg_engine *e, int64_t n, const int32_t *gro
   int rc = run_derive(e);
   if (rc != RG_OK) return rc;
   std::vector<int> order; std::vector<size_t> startOf;
-  level_order(groups, n, order, startOf);
+  level_order(e, groups, n, order, startOf);
   TmpBuf tb;
   int *dg = tb.get<int>(n), *dp = tb.get<int>(n), *dord = tb.get<int>(n), *dt = tb.get<int>(ne);
   u64 *dcm = tb.get<u64>(ne);
