@@ -461,6 +461,7 @@ static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
   def("PARTPERIOD", c.partPeriod); def("PARTJITTER", c.partJitter);
   def("CHURNPERIOD", c.churnPeriod); def("CHURNDISC", c.churnDisc); def("CHURNRESTART", c.churnRestart); def("CHURNCRASH", c.churnCrash);
   def("ACCTBYTES", c.acctBytes);
+  if (const char *x = getenv("RAFTGPU_SPEC_DEFS")) { std::string t = x; size_t i = 0; while (i < t.size()) { size_t j = t.find(' ', i); if (j == std::string::npos) j = t.size(); if (j > i) opts.push_back(t.substr(i, j - i)); i = j + 1; } }   // tuning aid: extra compiler options
   // code objects already compiled in this process, by option string: engines of one configuration share the compile
   static std::mutex cacheMu;
   static std::unordered_map<std::string, std::vector<char>> cache;

@@ -160,7 +160,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   const int wave = (int)(threadIdx.x >> 6);
 
   const int g0 = classA ? set * 4 * c.gwA : c.nbA * 4 * c.gwA + (set - c.nbA) * 4 * c.gwB;   // the set's first group: always < G
-  constexpr int RING = 4;
+#ifndef RG_RING
+#define RG_RING 4
+#endif
+  constexpr int RING = RG_RING;
   __shared__ int ringIdx[RING][256];
   constexpr int GPBPAD = (GPB + 31) & ~31;
   // Which of the set's groups the lane works on.  A wave makes as many passes as its busiest group has events, and
