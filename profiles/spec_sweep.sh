@@ -10,6 +10,6 @@ for o in "$@"; do
 import json, sys
 d = json.load(open(sys.argv[2]))
 c = d["counters_per_step"]
-print("%-40s %.4e group-ticks/s  kernel %.2f ms  committed %d  flagged %d" % (sys.argv[1] or "(none)", d["value"], d["roofline"]["kernel_ms"], c["entries_committed"], d["flagged_groups"]))
+print("%-60s %.4e group-ticks/s  %s %.2f ms  committed %d  flagged %d" % (sys.argv[1] or "(none)", d["value"], d["roofline"]["kernel"], d["roofline"]["kernel_ms"], c["entries_committed"], d["flagged_groups"]))
 PY
 done
