@@ -475,10 +475,125 @@ def vote_test_reads_the_voters_own_entry(mk):
     assert e.request_vote(0, 2, 5, 1, 1, 1) == (5, False)     # LastLogIndex 1 < commitIndex 2 at equal terms
 
 
+def _net_call(seed, group, s, j, seq, req_drop, reply_drop, reply_delay):
+    """One Call on an unreliable net, restated from docs/LOCKSTEP.md "Network": (what happens, ms the sender waits)."""
+    key = _sm64(_sm64(seed) ^ group)
+    h = _sm64(key ^ (2 << 56) ^ (((s << 8) | j) << 32) ^ seq)
+    d = (((h >> 48) & 0xFF) * 27) >> 8                       # labrpc.go:222: 0..26 ms
+    permille = lambda x: (x * 1000) >> 16
+    if permille(h & 0xFFFF) < req_drop:
+        return "lost", min(d, 25)                            # labrpc.go:226-229: Call returns false after the short delay
+    if permille((h >> 16) & 0xFFFF) < reply_drop:
+        return "reply lost", min(d, 25)                      # labrpc.go:273-275
+    if d >= 25 or permille((h >> 32) & 0xFFFF) < reply_delay:
+        return "late", 25                                    # raft.go:473: the sender has given up
+    return "round trip", d
+
+
+def a_failed_call_costs_its_short_delay(mk):
+    """labrpc.go:222-229, 273-275 with raft.go:469-474, 521: the leader's select waits for each Call until it returns --
+    false right after the net's 0..26 ms delay when the net drops the request or the reply -- or 25 ms, and
+    heartbeatTimer is set when the round's Calls are through.  Twelve rounds of a leader on a net that drops 30 % of the
+    requests and 30 % of the replies, every Call worked out here from the hash alone: what reached whom, and how long
+    the round took."""
+    seed = 1
+    e = mk(n_groups=1, n_peers=3, log_cap=64, seed=seed)
+    e.step(30)
+    assert e.get_state(0, 0) == (1, True)
+    e.set_unreliable(300, 300, 0)
+    kinds, rounds = set(), 0
+    for _ in range(400):
+        if rounds == 12:
+            break
+        assert e.get_state(0, 0)[1]
+        q = int(e.read("roundseq")[0, 0])
+        e.start(0, 0, 1000 + e.now())
+        timers, match = e.read("timer")[0].copy(), e.read("matchindex")[0, 0].copy()
+        e.step(1)
+        if int(e.read("roundseq")[0, 0]) == q:
+            continue
+        assert int(e.read("roundseq")[0, 0]) == q + 1
+        now, cost = (e.now() - 1) * 10, 0
+        length = int(e.read("loglen")[0, 0])
+        for j in (1, 2):
+            kind, ms = _net_call(seed, 0, 0, j, q, 300, 300, 0)
+            kinds.add(kind)
+            cost += ms
+            if kind == "lost":
+                assert e.read("timer")[0, j] == timers[j]                       # the handler never ran
+            else:
+                assert e.read("timer")[0, j] == now and e.read("loglen")[0, j] == length
+            if kind == "round trip":
+                assert e.read("matchindex")[0, 0, j] == length - 1
+            else:
+                assert e.read("matchindex")[0, 0, j] == match[j]                # the leader heard nothing
+        assert e.read("hbtimer")[0, 0] == now + cost
+        rounds += 1
+    assert rounds == 12 and kinds == {"lost", "reply lost", "late", "round trip"}
+    return e
+
+
+def partitions_and_commands_follow_their_hashes(mk):
+    """The device-generated workload, restated from docs/LOCKSTEP.md: a reshuffle takes ONE hash (stream 4, the
+    group's reshuffle number) -- bit p is peer p's side, the upper half scaled to the jitter gives the next reshuffle's
+    tick -- and the client's n-th command is hash(key, 3, 0, n).  Group 2 of 4, so the key is not group 0's."""
+    seed, g, period, jitter = 3, 2, 50, 20
+    e = mk(n_groups=4, n_peers=5, log_cap=64, seed=seed, part_period=period, part_jitter=jitter, start_period=7, start_first_tick=3, start_max=20)
+    key = _sm64(_sm64(seed) ^ g)
+    assert (int(e.read("partnext")[g]), int(e.read("partepoch")[g])) == (period, 0)
+    for _ in range(6):
+        at, epoch = int(e.read("partnext")[g]), int(e.read("partepoch")[g])
+        e.step(at + 1 - e.now())
+        h = _sm64(key ^ (4 << 56) ^ (epoch << 32))
+        assert e.read("side")[g].tolist() == [(h >> p) & 1 for p in range(5)]
+        assert int(e.read("partnext")[g]) == at + period + (((h >> 32) * jitter) >> 32)
+        assert int(e.read("partepoch")[g]) == epoch + 1
+    e.step(400)
+    assert int(e.read("startseq")[g]) == 20
+    cmds = [_sm64(key ^ (3 << 56) ^ n) for n in range(20)]
+    have = e.read("logcmd")[g]
+    lens = e.read("loglen")[g]
+    assert int(lens.max()) == 21
+    for p in range(5):
+        assert [int(x) for x in have[p][1:int(lens[p])]] == cmds[:int(lens[p]) - 1]   # every log is a prefix of the command sequence
+    return e
+
+
+def churn_follows_its_hashes(mk):
+    """test_test.go:893-919 as docs/LOCKSTEP.md fixes it: every churn_period ticks three hashes decide, in this order,
+    whether a peer is disconnected, whether one is restarted (if dead) and connected, whether one is crashed.  The
+    connectivity and liveness of a group replayed here from the hashes alone over 39 churn ticks."""
+    seed, g, P, period = 5, 1, 5, 20
+    rates = (300, 600, 300)
+    e = mk(n_groups=3, n_peers=P, log_cap=64, seed=seed, churn_period=period, churn_disconnect_permille=rates[0],
+           churn_restart_permille=rates[1], churn_crash_permille=rates[2])
+    key = _sm64(_sm64(seed) ^ g)
+    conn, dead, seen = [1] * P, [0] * P, set()
+    for it in range(1, 40):
+        e.step(it * period + 1 - e.now())
+        hs = [_sm64(key ^ (5 << 56) ^ (it << 32) ^ k) for k in range(3)]
+        hit = [(h & 0xFFFFF) % 1000 < r for h, r in zip(hs, rates)]
+        who = [(h >> 32) % P for h in hs]
+        if hit[0]:
+            conn[who[0]] = 0
+            seen.add("disconnect")
+        if hit[1]:
+            if dead[who[1]]:
+                seen.add("restart")
+            dead[who[1]], conn[who[1]] = 0, 1
+        if hit[2] and not dead[who[2]]:
+            conn[who[2]], dead[who[2]] = 0, 1
+            seen.add("crash")
+        assert e.read("connected")[g].tolist() == conn and e.read("dead")[g].tolist() == dead, "churn tick %d" % it
+    assert seen == {"disconnect", "restart", "crash"}
+    return e
+
+
 CASES = {f.__name__: f for f in (
     boot_and_three_starts, conflict_reply, append_truncates_unconditionally, leader_backoff, commit_rule,
     vote_compares_commit_index, restore_repersists_one_entry, start_on_isolated_leader, stop_rule,
     applied_entry_overwritten, same_term_vote_request_demotes_leader, candidate_steps_down_without_adopting_term,
     leader_adopts_term_keeps_vote, votes_are_counted_per_reply, late_vote_replies_are_lost,
     failed_candidate_retries_same_term, rng_draw_points, apply_stream_keeps_what_was_applied,
-    apply_ring_overrun_is_reported, vote_test_reads_the_voters_own_entry)}
+    apply_ring_overrun_is_reported, vote_test_reads_the_voters_own_entry, a_failed_call_costs_its_short_delay,
+    partitions_and_commands_follow_their_hashes, churn_follows_its_hashes)}
