@@ -589,6 +589,37 @@ def churn_follows_its_hashes(mk):
     return e
 
 
+def election_loop_sleeps_with_its_slack(mk):
+    """raft.go:548-668 under docs/LOCKSTEP.md "Time": an idle follower's election loop wakes, finds its timer not run
+    out, and sleeps 50 ms plus a seeded slack of 0..3 ms -- the 32-bit mix of (key, peer, now) restated here.  The
+    wake-up times of two followers over 120 ticks, one tick per launch, so nothing is hidden by catching up."""
+    m32 = 0xFFFFFFFF
+
+    def slack(key, p, now):
+        h = ((key & m32) ^ ((p * 0x9E3779B1) & m32) ^ ((now * 0x85EBCA6B) & m32)) & m32
+        h ^= h >> 16
+        h = (h * 0x7FEB352D) & m32
+        h ^= h >> 15
+        h = (h * 0x846CA68B) & m32
+        h ^= h >> 16
+        return h >> 30
+
+    seed, g = 9, 1
+    e = mk(n_groups=2, n_peers=3, log_cap=16, seed=seed)
+    key = _sm64(_sm64(seed) ^ g)
+    el, seen = e.read("elnext")[g].tolist(), set()
+    assert el == [0, 0, 0]
+    for t in range(120):
+        e.step(1)
+        for p in (1, 2):
+            if el[p] <= 10 * t:
+                seen.add(slack(key, p, 10 * t))
+                el[p] = 10 * t + 50 + slack(key, p, 10 * t)
+        assert e.read("elnext")[g].tolist()[1:] == el[1:], "tick %d" % t
+    assert seen == {0, 1, 2, 3} and e.get_state(g, 0) == (1, True)
+    return e
+
+
 CASES = {f.__name__: f for f in (
     boot_and_three_starts, conflict_reply, append_truncates_unconditionally, leader_backoff, commit_rule,
     vote_compares_commit_index, restore_repersists_one_entry, start_on_isolated_leader, stop_rule,
@@ -596,4 +627,5 @@ CASES = {f.__name__: f for f in (
     leader_adopts_term_keeps_vote, votes_are_counted_per_reply, late_vote_replies_are_lost,
     failed_candidate_retries_same_term, rng_draw_points, apply_stream_keeps_what_was_applied,
     apply_ring_overrun_is_reported, vote_test_reads_the_voters_own_entry, a_failed_call_costs_its_short_delay,
-    partitions_and_commands_follow_their_hashes, churn_follows_its_hashes)}
+    partitions_and_commands_follow_their_hashes, churn_follows_its_hashes,
+    election_loop_sleeps_with_its_slack)}
