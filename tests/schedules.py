@@ -4,7 +4,7 @@ thousands of groups at once.  Ticks are 10 ms; sleeps of the reference become ga
 import random
 
 from raft_amd._abi import (OP_CONNECT, OP_CRASH, OP_DISCONNECT, OP_PICK_LEADER, OP_PICK_OTHER, OP_PICK_RANDOM,
-                           OP_RESTART_IF_FEWER, OP_START, OP_START_ALL, OP_START_ANY, SEL_ALL, SEL_REG)
+                           OP_RESTART, OP_RESTART_IF_FEWER, OP_START, OP_START_ALL, OP_START_ANY, SEL_ALL, SEL_REG)
 
 
 def backup_2b(gap=400):
@@ -63,5 +63,146 @@ def figure8_2c(iters=60, seed=8):
     ops.append((t + 250, OP_START_ANY, 0, 9999))
     return ops, t + 400
 
+
+def _one(ops, t, cmd, gap):
+    """cfg.one(cmd, n, retry) (config.go:430-477): ask whoever leads, then leave `gap` ticks for the agreement."""
+    ops.append((t, OP_START_ANY, 0, cmd))
+    return t + gap
+
+
+def reelection_2a(gap=300):
+    """TestReElection2A (test_test.go:53-87), 3 peers.  Returns the tick of its checkNoLeader as well."""
+    ops, t = [], 100
+    ops += [(t, OP_PICK_LEADER, 0, 0), (t, OP_DISCONNECT, SEL_REG(0, 0), 0)]      # if the leader disconnects, a new one should be elected
+    t += gap
+    ops.append((t, OP_CONNECT, SEL_REG(0, 0), 0))                                 # the old leader rejoins
+    t += 100
+    ops += [(t, OP_PICK_LEADER, 1, 0), (t, OP_DISCONNECT, SEL_REG(1, 0), 0), (t, OP_DISCONNECT, SEL_REG(1, 1), 0)]   # no quorum
+    t += 200                                                                      # 2 * RaftElectionTimeout
+    no_leader_at = t
+    ops.append((t, OP_CONNECT, SEL_REG(1, 1), 0))                                 # a quorum arises
+    t += gap
+    ops.append((t, OP_CONNECT, SEL_REG(1, 0), 0))                                 # re-join of the last node
+    return ops, t + 100, no_leader_at
+
+
+def fail_agree_2b(gap=60):
+    """TestFailAgree2B (test_test.go:147-179), 3 peers: agreement despite a disconnected follower, which then catches up."""
+    ops, t = [], 100
+    t = _one(ops, t, 101, gap)
+    ops += [(t, OP_PICK_LEADER, 0, 0), (t, OP_DISCONNECT, SEL_REG(0, 1), 0)]
+    t = _one(ops, t + 1, 102, gap)
+    t = _one(ops, t, 103, gap)
+    t += 100                                                                      # RaftElectionTimeout
+    t = _one(ops, t, 104, gap)
+    t = _one(ops, t, 105, gap)
+    ops.append((t, OP_CONNECT, SEL_REG(0, 1), 0))
+    t += 300                                                                      # the returning peer's term forces an election; one() retries
+    t = _one(ops, t, 106, gap)
+    t += 100
+    t = _one(ops, t, 107, 2 * gap)
+    return ops, t, 7
+
+
+def fail_no_agree_2b(gap=300):
+    """TestFailNoAgree2B (test_test.go:181-230), 5 peers: three followers leave, the leader's entry must not commit;
+    after the repair the group agrees again."""
+    ops, t = [], 100
+    t = _one(ops, t, 10, 60)
+    ops.append((t, OP_PICK_LEADER, 0, 0))
+    ops += [(t, OP_DISCONNECT, SEL_REG(0, k), 0) for k in (1, 2, 3)]
+    ops.append((t + 1, OP_START, SEL_REG(0, 0), 20))
+    t += 200                                                                      # 2 * RaftElectionTimeout
+    ops += [(t, OP_CONNECT, SEL_REG(0, k), 0) for k in (1, 2, 3)]
+    t += gap                                                                      # checkOneLeader
+    t = _one(ops, t, 30, 60)
+    t = _one(ops, t, 1000, 100)
+    return ops, t, None
+
+
+def rejoin_2b(gap=300):
+    """TestRejoin2B (test_test.go:333-369), 3 peers: a partitioned leader piles up entries, its successor is
+    partitioned in turn, the old leader comes back."""
+    ops, t = [], 100
+    t = _one(ops, t, 101, 60)
+    ops += [(t, OP_PICK_LEADER, 0, 0), (t, OP_DISCONNECT, SEL_REG(0, 0), 0)]
+    ops += [(t + 1 + i, OP_START, SEL_REG(0, 0), 102 + i) for i in range(3)]      # the old leader tries to agree on some entries
+    t += gap
+    t = _one(ops, t, 103, 60)                                                     # new leader commits, also for index 2
+    ops += [(t, OP_PICK_LEADER, 1, 0), (t, OP_DISCONNECT, SEL_REG(1, 0), 0), (t, OP_CONNECT, SEL_REG(0, 0), 0)]
+    t += gap
+    t = _one(ops, t, 104, 60)
+    ops.append((t, OP_CONNECT, SEL_REG(1, 0), 0))                                 # all together now
+    t += gap
+    t = _one(ops, t, 105, 100)
+    return ops, t, 4
+
+
+def persist1_2c(gap=300):
+    """TestPersist12C (test_test.go:553-597), 3 peers: everyone is crashed and restarted, then leaders and a follower
+    in turn, with agreements in between."""
+    ops, t = [], 100
+    t = _one(ops, t, 11, 60)
+    ops += [(t, OP_RESTART, k, 0) for k in range(3)] + [(t, OP_CONNECT, k, 0) for k in range(3)]   # crash and re-start all
+    t += gap
+    t = _one(ops, t, 12, 60)
+    ops += [(t, OP_PICK_LEADER, 0, 0), (t, OP_RESTART, SEL_REG(0, 0), 0), (t, OP_CONNECT, SEL_REG(0, 0), 0)]
+    t += gap
+    t = _one(ops, t, 13, 60)
+    ops += [(t, OP_PICK_LEADER, 1, 0), (t, OP_DISCONNECT, SEL_REG(1, 0), 0)]
+    t += gap
+    t = _one(ops, t, 14, 60)
+    ops += [(t, OP_RESTART, SEL_REG(1, 0), 0), (t, OP_CONNECT, SEL_REG(1, 0), 0)]
+    t += gap                                                                      # cfg.wait(4, servers, -1)
+    ops += [(t, OP_PICK_LEADER, 2, 0), (t, OP_DISCONNECT, SEL_REG(2, 1), 0)]      # i3 = leader + 1
+    t = _one(ops, t + 1, 15, 60)
+    ops += [(t, OP_RESTART, SEL_REG(2, 1), 0), (t, OP_CONNECT, SEL_REG(2, 1), 0)]
+    t += 60
+    t = _one(ops, t, 16, 100)
+    return ops, t, 6
+
+
+def persist2_2c(gap=300, iters=5):
+    """TestPersist22C (test_test.go:599-643), 5 peers: rolling disconnects and restarts around three agreements per round."""
+    ops, t, index = [], 100, 1
+    for _ in range(iters):
+        t = _one(ops, t, 10 + index, 60)
+        index += 1
+        ops.append((t, OP_PICK_LEADER, 0, 0))
+        ops += [(t, OP_DISCONNECT, SEL_REG(0, k), 0) for k in (1, 2)]
+        t = _one(ops, t + 1, 10 + index, 60)
+        index += 1
+        ops += [(t, OP_DISCONNECT, SEL_REG(0, k), 0) for k in (0, 3, 4)]
+        ops += [(t, OP_RESTART, SEL_REG(0, k), 0) for k in (1, 2)] + [(t, OP_CONNECT, SEL_REG(0, k), 0) for k in (1, 2)]
+        t += 100                                                                  # RaftElectionTimeout
+        ops += [(t, OP_RESTART, SEL_REG(0, 3), 0), (t, OP_CONNECT, SEL_REG(0, 3), 0)]
+        t += gap
+        t = _one(ops, t, 10 + index, 60)
+        index += 1
+        ops += [(t, OP_CONNECT, SEL_REG(0, 4), 0), (t, OP_CONNECT, SEL_REG(0, 0), 0)]
+        t += gap
+    t = _one(ops, t, 1000, 100)
+    return ops, t, index
+
+
+def persist3_2c(gap=300):
+    """TestPersist32C (test_test.go:645-673), 3 peers: partitioned leader and one follower crash, the leader restarts."""
+    ops, t = [], 100
+    t = _one(ops, t, 101, 60)
+    ops += [(t, OP_PICK_LEADER, 0, 0), (t, OP_DISCONNECT, SEL_REG(0, 2), 0)]
+    t = _one(ops, t + 1, 102, 60)
+    ops += [(t, OP_CRASH, SEL_REG(0, 0), 0), (t, OP_CRASH, SEL_REG(0, 1), 0), (t, OP_CONNECT, SEL_REG(0, 2), 0),
+            (t, OP_RESTART, SEL_REG(0, 0), 0), (t, OP_CONNECT, SEL_REG(0, 0), 0)]
+    t += gap
+    t = _one(ops, t, 103, 60)
+    ops += [(t, OP_RESTART, SEL_REG(0, 1), 0), (t, OP_CONNECT, SEL_REG(0, 1), 0)]
+    t += 100
+    t = _one(ops, t, 104, 100)
+    return ops, t, 4
+
+
+# name -> (peers, schedule); the schedules return (ops, ticks, commitIndex every peer should end on, or None)
+MORE = {"FailAgree2B": (3, fail_agree_2b), "FailNoAgree2B": (5, fail_no_agree_2b), "Rejoin2B": (3, rejoin_2b),
+        "Persist12C": (3, persist1_2c), "Persist22C": (5, persist2_2c), "Persist32C": (3, persist3_2c)}
 
 ALL = {"Backup2B": backup_2b, "Figure82C": figure8_2c}

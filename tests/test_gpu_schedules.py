@@ -72,3 +72,31 @@ def test_schedule_on_16384_groups_in_one_launch(name):
         assert total["ae_conflicts"] >= G
         commit = e.read("commit")
         assert ((commit == 102).all(axis=1)).mean() > 0.85
+
+
+@pytest.mark.parametrize("name", sorted(schedules.MORE) + ["ReElection2A"])
+def test_more_scenarios_on_16384_groups_in_one_launch(name):
+    """The other scenario tables (tests/schedules.py): one launch on 16,384 groups, every group's digest and flags
+    against the oracle's."""
+    if name == "ReElection2A":
+        P, (ops, ticks, _) = 3, schedules.reelection_2a()
+    else:
+        P, fn = schedules.MORE[name]
+        ops, ticks, _ = fn()
+    G = 16384
+    kw = dict(n_groups=G, n_peers=P, log_cap=64, seed=33)
+    e = _mk(**kw)
+    e.set_schedule(ops)
+    e.step(ticks)
+    h, fl = e.state_hash(), e.read("gflags")
+    total = dict.fromkeys(e.counters(), 0)
+    for first in range(0, G, 4096):
+        o = _oracle(**dict(kw, n_groups=4096, group_base=first))
+        o.set_schedule(ops)
+        o.step_mt(ticks, 16)
+        assert np.array_equal(o.state_hash(), h[first:first + 4096]), "groups %d.." % first
+        assert np.array_equal(o.read("gflags"), fl[first:first + 4096])
+        for k, v in o.counters().items():
+            total[k] += v
+        o.close()
+    assert total == e.counters()

@@ -96,3 +96,40 @@ def test_figure8_2c_on_every_group(mk):
     agreed = [bool((commit[g] == commit[g, 0]).all() and commit[g, 0] >= 2 and
                    len({int(lc[g, p, commit[g, p]]) for p in range(5)}) == 1) for g in range(64)]
     assert sum(agreed) >= 0.9 * 64
+
+
+@pytest.mark.parametrize("name", sorted(schedules.MORE))
+def test_more_scenarios_on_every_group(mk, name):
+    """TestFailAgree2B, TestFailNoAgree2B, TestRejoin2B, TestPersist1/2/32C as op tables, 512 groups each: where the
+    reference's test expects every server to hold the agreed entries, (nearly) every group ends with every peer's
+    commitIndex on the last one; where it expects an entry NOT to commit, it is committed nowhere at that point."""
+    P, fn = schedules.MORE[name]
+    ops, ticks, want = fn()
+    e = mk(n_groups=512, n_peers=P, log_cap=64, seed=41)
+    e.set_schedule(ops)
+    if name == "FailNoAgree2B":
+        repair = min(t for t, op, a, b in ops if op == OP_CONNECT)
+        e.step_mt(repair, 8)
+        assert int(e.read("commit").max()) <= 1          # nCommitted(2) == 0, test_test.go:206-209
+        e.step_mt(ticks - repair, 8)
+        commit = e.read("commit")
+        assert ((commit.min(axis=1) >= 3) & (commit.max(axis=1) <= 4)).mean() > 0.95      # 10, (20 kept or forgotten), 30, 1000
+    else:
+        e.step_mt(ticks, 8)
+        assert (e.read("commit") == want).all(axis=1).mean() > 0.95
+    assert e.safety_flags() == (0, 0)
+
+
+def test_reelection_2a_on_every_group(mk):
+    """TestReElection2A: no connected peer leads while there is no quorum; one leader and one term at the end."""
+    ops, ticks, no_leader_at = schedules.reelection_2a()
+    G = 512
+    e = mk(n_groups=G, n_peers=3, log_cap=16, seed=41)
+    e.set_schedule(ops)
+    e.step_mt(no_leader_at, 8)
+    leads = np.array([[e.get_state(g, p)[1] for p in range(3)] for g in range(G)])
+    assert not (leads & e.read("connected").astype(bool)).any()              # checkNoLeader, test_test.go:76
+    e.step_mt(ticks - no_leader_at, 8)
+    leads = np.array([[e.get_state(g, p)[1] for p in range(3)] for g in range(G)])
+    assert (leads.sum(axis=1) == 1).mean() > 0.98
+    assert e.safety_flags() == (0, 0)
