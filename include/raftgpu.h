@@ -276,6 +276,7 @@ enum {
   RG_OP_PICK_RANDOM,       /* a: register := hash(group, op number, b) mod n_peers */
   RG_OP_PICK_OTHER,        /* a: register := the first connected live peer after selector b, in cyclic order, or none */
   RG_OP_RESTART_IF_FEWER,  /* a: selector, b: n; if that peer is dead and fewer than n peers are alive: start1 + connect  test_test.go:718-725 */
+  RG_OP_CONNECT_IF_FEWER,  /* a: selector, b: n; if that peer is disconnected and fewer than n peers are connected: connect  test_test.go:805-811 */
   RG_OP_END
 };
 typedef struct rg_sched_op { int32_t tick, op, a, b; } rg_sched_op;

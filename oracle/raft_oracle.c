@@ -553,6 +553,12 @@ static void sched_op(ro_engine *e, ctr_t *c, group_t *g, const rg_sched_op *op, 
       if ((tgt == p || tgt == -2) && g->peer[p].dead && alive < op->b) { start1(e, c, g, p, tick * RG_TICK_MS); g->peer[p].connected = 1; }
     break;
   }
+  case RG_OP_CONNECT_IF_FEWER: {                                            /* test_test.go:805-811 */
+    int up = 0;
+    for (int p = 0; p < P; p++) up += g->peer[p].connected != 0;
+    for (int p = 0; p < P; p++) if ((tgt == p || tgt == -2) && up < op->b) g->peer[p].connected = 1;
+    break;
+  }
   case RG_OP_START:                                                         /* rf.Start on one peer */
     if (tgt >= 0 && !g->peer[tgt].dead) start_cmd(e, c, g, tgt, stream_hash(g->key, STREAM_CMD, 1, (uint32_t)op->b), &idx, &term, &ok);
     break;

@@ -53,7 +53,7 @@ START_ONE, START_ALL = 0, 1
 
 # scenario schedule ops and selectors
 (OP_CONNECT, OP_DISCONNECT, OP_CRASH, OP_RESTART, OP_START, OP_START_ANY, OP_START_ALL, OP_PICK_LEADER, OP_PICK_RANDOM,
- OP_PICK_OTHER, OP_RESTART_IF_FEWER) = range(1, 12)
+ OP_PICK_OTHER, OP_RESTART_IF_FEWER, OP_CONNECT_IF_FEWER) = range(1, 13)
 SEL_ALL = 0x80
 
 

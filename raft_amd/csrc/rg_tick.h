@@ -519,6 +519,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           const bool me = due && (tgt == peer || tgt == -2);
           if (kind == RG_OP_CONNECT && me) r.flags |= F_CONNECTED;
           if (kind == RG_OP_DISCONNECT && me) r.flags &= ~F_CONNECTED;
+          if (wave_any(kind == RG_OP_CONNECT_IF_FEWER)) {
+            const int up = __popc(G.ballot(valid && r.has(F_CONNECTED)));
+            if (kind == RG_OP_CONNECT_IF_FEWER && me && up < op.b) r.flags |= F_CONNECTED;
+          }
           if (kind == RG_OP_CRASH && me) { r.flags &= ~F_CONNECTED; r.flags |= F_DEAD; }
           const int alive = __popc(G.ballot(valid && !r.has(F_DEAD)));
           const bool again = kind == RG_OP_RESTART_IF_FEWER && me && r.has(F_DEAD) && alive < op.b;

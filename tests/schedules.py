@@ -3,7 +3,7 @@ group of an engine executes on its own peers inside the tick kernel, so one laun
 thousands of groups at once.  Ticks are 10 ms; sleeps of the reference become gaps between ops."""
 import random
 
-from raft_amd._abi import (OP_CONNECT, OP_CRASH, OP_DISCONNECT, OP_PICK_LEADER, OP_PICK_OTHER, OP_PICK_RANDOM,
+from raft_amd._abi import (OP_CONNECT, OP_CONNECT_IF_FEWER, OP_CRASH, OP_DISCONNECT, OP_PICK_LEADER, OP_PICK_OTHER, OP_PICK_RANDOM,
                            OP_RESTART, OP_RESTART_IF_FEWER, OP_START, OP_START_ALL, OP_START_ANY, SEL_ALL, SEL_REG)
 
 
@@ -199,6 +199,42 @@ def persist3_2c(gap=300):
     t += 100
     t = _one(ops, t, 104, 100)
     return ops, t, 4
+
+
+def figure8_unreliable_2c(iters=400, seed=9):
+    """TestFigure8Unreliable2C (test_test.go:770-823), 5 peers on an unreliable net: every iteration asks every peer
+    to Start a command, waits a short or (one time in ten) a long while, disconnects the connected leader half of the
+    time, and reconnects a random peer when fewer than three are connected; at the end all are reconnected and one
+    more command must go through.  Returns the tick of the iteration at which the reference turns long reordering on
+    (a host verb: cfg.setlongreordering, config.go:296-298) as well."""
+    rnd = random.Random(seed)
+    ops, t, reorder_at = [(60, OP_START_ANY, 0, 1)], 120, None
+    for i in range(iters):
+        if i == iters // 5:
+            reorder_at = t
+        ops.append((t, OP_START_ALL, 3, 100 + i))
+        ops.append((t, OP_PICK_LEADER, 0, 0))                                   # a connected peer that accepted
+        t += rnd.randrange(0, 50) if rnd.randrange(1000) < 100 else rnd.randrange(0, 13) // 10 + (rnd.randrange(10) < 6)
+        if rnd.randrange(1000) < 500:
+            ops.append((t, OP_DISCONNECT, SEL_REG(0, 0), 0))
+        ops.append((t, OP_PICK_RANDOM, 1, i))
+        ops.append((t, OP_CONNECT_IF_FEWER, SEL_REG(1, 0), 3))
+    ops.append((t, OP_CONNECT, SEL_ALL, 0))
+    ops.append((t + 400, OP_START_ANY, 0, 9999))
+    return ops, t + 600, reorder_at
+
+
+def unreliable_agree_2c(iters=49):
+    """TestUnreliableAgree2C (test_test.go:741-768), 5 peers on an unreliable net: five concurrent cfg.one() per
+    iteration; the reference then makes the net reliable (a host verb) and wants one more agreement on all servers.
+    Returns the tick at which the net becomes reliable."""
+    ops, t = [], 150
+    for it in range(1, iters + 1):
+        ops += [(t, OP_START_ANY, 0, 100 * it + j) for j in range(4)] + [(t, OP_START_ANY, 0, it)]
+        t += 8
+    reliable_at = t
+    ops.append((t + 300, OP_START_ANY, 0, 100))
+    return ops, t + 500, reliable_at
 
 
 # name -> (peers, schedule); the schedules return (ops, ticks, commitIndex every peer should end on, or None)

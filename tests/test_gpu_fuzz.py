@@ -41,7 +41,7 @@ def _random_ops(rng, peers, until):
     regs_set = set()
     while t < until:
         kind = rng.choice(["pick_leader", "pick_random", "pick_other", "connect", "disconnect", "crash", "restart", "start", "start_any",
-                           "start_all", "restart_if_fewer"])
+                           "start_all", "restart_if_fewer", "connect_if_fewer"])
         sel = rng.choice([rng.randrange(peers), _abi.SEL_ALL] + [_abi.SEL_REG(r, rng.randrange(peers)) for r in regs_set])
         r = rng.randrange(4)
         if kind == "pick_leader":
@@ -58,6 +58,8 @@ def _random_ops(rng, peers, until):
             ops.append((t, _abi.OP_START, sel, rng.randrange(1 << 20)))
         elif kind == "restart_if_fewer":
             ops.append((t, _abi.OP_RESTART_IF_FEWER, sel, rng.randrange(1, peers + 2)))
+        elif kind == "connect_if_fewer":
+            ops.append((t, _abi.OP_CONNECT_IF_FEWER, sel, rng.randrange(1, peers + 2)))
         else:
             ops.append((t, {"connect": _abi.OP_CONNECT, "disconnect": _abi.OP_DISCONNECT, "crash": _abi.OP_CRASH, "restart": _abi.OP_RESTART}[kind], sel, 0))
         t += rng.choice([0, 0, 1, 3, 10, 40, 120])

@@ -100,3 +100,34 @@ def test_more_scenarios_on_16384_groups_in_one_launch(name):
             total[k] += v
         o.close()
     assert total == e.counters()
+
+
+@pytest.mark.parametrize("name", ["Figure8Unreliable2C", "UnreliableAgree2C"])
+def test_unreliable_scenarios_on_16384_groups(name):
+    """The two scenarios that change the net half way (cfg.setlongreordering / cfg.setunreliable between two launches):
+    16,384 groups, every digest and flag word against the oracle's."""
+    if name == "Figure8Unreliable2C":
+        (ops, ticks, at), rates, cap = schedules.figure8_unreliable_2c(), (100, 100, 667), 1024
+    else:
+        (ops, ticks, at), rates, cap = schedules.unreliable_agree_2c(), (0, 0, 0), 512
+    G = 16384
+    kw = dict(n_groups=G, n_peers=5, log_cap=cap, seed=34, req_drop_permille=100, reply_drop_permille=100)
+    e = _mk(**kw)
+    e.set_schedule(ops)
+    e.step(at)
+    e.set_unreliable(*rates)
+    e.step(ticks - at)
+    h, fl = e.state_hash(), e.read("gflags")
+    total = dict.fromkeys(e.counters(), 0)
+    for first in range(0, G, 4096):
+        o = _oracle(**dict(kw, n_groups=4096, group_base=first))
+        o.set_schedule(ops)
+        o.step_mt(at, 16)
+        o.set_unreliable(*rates)
+        o.step_mt(ticks - at, 16)
+        assert np.array_equal(o.state_hash(), h[first:first + 4096]), "groups %d.." % first
+        assert np.array_equal(o.read("gflags"), fl[first:first + 4096])
+        for k, v in o.counters().items():
+            total[k] += v
+        o.close()
+    assert total == e.counters()

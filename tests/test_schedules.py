@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from raft_amd import _abi
-from raft_amd._abi import (OP_CONNECT, OP_CRASH, OP_DISCONNECT, OP_PICK_LEADER, OP_PICK_OTHER, OP_PICK_RANDOM, OP_RESTART,
+from raft_amd._abi import (OP_CONNECT, OP_CONNECT_IF_FEWER, OP_CRASH, OP_DISCONNECT, OP_PICK_LEADER, OP_PICK_OTHER, OP_PICK_RANDOM, OP_RESTART,
                            OP_RESTART_IF_FEWER, OP_START, OP_START_ALL, OP_START_ANY, SEL_ALL, SEL_REG)
 from tests import schedules
 
@@ -132,4 +132,44 @@ def test_reelection_2a_on_every_group(mk):
     e.step_mt(ticks - no_leader_at, 8)
     leads = np.array([[e.get_state(g, p)[1] for p in range(3)] for g in range(G)])
     assert (leads.sum(axis=1) == 1).mean() > 0.98
+    assert e.safety_flags() == (0, 0)
+
+
+def test_connect_if_fewer(mk):
+    """test_test.go:805-811: a disconnected peer is reconnected only while fewer than n peers are connected."""
+    e = mk(n_groups=2, n_peers=5, log_cap=16, seed=1)
+    e.set_schedule([(5, OP_DISCONNECT, 0, 0), (5, OP_DISCONNECT, 1, 0), (6, OP_CONNECT_IF_FEWER, 0, 3),     # 3 connected: not fewer than 3
+                    (7, OP_DISCONNECT, 2, 0), (8, OP_CONNECT_IF_FEWER, 0, 3),                                # 2 connected: peer 0 comes back
+                    (9, OP_CONNECT_IF_FEWER, SEL_ALL, 5), (10, OP_CONNECT_IF_FEWER, 4, 9)])                   # 3 connected < 5: everyone; a connected peer stays
+    e.step(7)
+    assert e.read("connected")[1].tolist() == [0, 0, 1, 1, 1]
+    e.step(2)
+    assert e.read("connected")[1].tolist() == [1, 0, 0, 1, 1]
+    e.step(2)
+    assert e.read("connected")[1].tolist() == [1, 1, 1, 1, 1]
+
+
+def test_figure8_unreliable_2c_on_every_group(mk):
+    """TestFigure8Unreliable2C: long reordering comes on a fifth of the way through (a host verb between two launches);
+    at the end (nearly) every group has agreed on the last command everywhere."""
+    ops, ticks, reorder_at = schedules.figure8_unreliable_2c()
+    e = mk(n_groups=512, n_peers=5, log_cap=1024, seed=41, req_drop_permille=100, reply_drop_permille=100)
+    e.set_schedule(ops)
+    e.step_mt(reorder_at, 8)
+    e.set_unreliable(100, 100, 667)
+    e.step_mt(ticks - reorder_at, 8)
+    commit = e.read("commit")
+    assert (commit.min(axis=1) == commit.max(axis=1)).mean() > 0.85 and int(commit.min()) >= 1
+    assert e.read("connected").all()
+
+
+def test_unreliable_agree_2c_on_every_group(mk):
+    """TestUnreliableAgree2C: 49 x 5 concurrent agreements on a lossy net, then one on a reliable net, on all servers."""
+    ops, ticks, reliable_at = schedules.unreliable_agree_2c()
+    e = mk(n_groups=512, n_peers=5, log_cap=512, seed=41, req_drop_permille=100, reply_drop_permille=100)
+    e.set_schedule(ops)
+    e.step_mt(reliable_at, 8)
+    e.set_unreliable(0, 0, 0)
+    e.step_mt(ticks - reliable_at, 8)
+    assert (e.read("commit") == 49 * 5 + 1).all(axis=1).mean() > 0.97
     assert e.safety_flags() == (0, 0)
