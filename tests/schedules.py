@@ -237,8 +237,26 @@ def unreliable_agree_2c(iters=49):
     return ops, t + 500, reliable_at
 
 
+def basic_agree_2b():
+    """TestBasicAgree2B (test_test.go:89-114), 3 peers: three agreements get indices 1, 2, 3 on every server."""
+    ops, t = [], 100
+    for i in range(3):
+        t = _one(ops, t, 100 * (i + 1), 40)
+    return ops, t, 3
+
+
+def concurrent_starts_2b():
+    """TestConcurrentStarts2B (test_test.go:232-331), 3 peers: Start(1) and five more Starts on the leader at once;
+    all six commit on every server in the leader's term."""
+    ops, t = [], 100
+    ops.append((t, OP_PICK_LEADER, 0, 0))
+    ops.append((t, OP_START, SEL_REG(0, 0), 1))
+    ops += [(t, OP_START, SEL_REG(0, 0), 100 + i) for i in range(5)]
+    return ops, t + 100, 6
+
+
 # name -> (peers, schedule); the schedules return (ops, ticks, commitIndex every peer should end on, or None)
-MORE = {"FailAgree2B": (3, fail_agree_2b), "FailNoAgree2B": (5, fail_no_agree_2b), "Rejoin2B": (3, rejoin_2b),
+MORE = {"BasicAgree2B": (3, basic_agree_2b), "ConcurrentStarts2B": (3, concurrent_starts_2b), "FailAgree2B": (3, fail_agree_2b), "FailNoAgree2B": (5, fail_no_agree_2b), "Rejoin2B": (3, rejoin_2b),
         "Persist12C": (3, persist1_2c), "Persist22C": (5, persist2_2c), "Persist32C": (3, persist3_2c)}
 
 ALL = {"Backup2B": backup_2b, "Figure82C": figure8_2c}

@@ -117,6 +117,8 @@ def test_more_scenarios_on_every_group(mk, name):
     else:
         e.step_mt(ticks, 8)
         assert (e.read("commit") == want).all(axis=1).mean() > 0.95
+    if name in ("BasicAgree2B", "ConcurrentStarts2B"):       # nothing disturbs these: every group, one term, every server
+        assert (e.read("commit") == want).all() and (e.read("applied") == want).all() and (e.read("term") == 1).all()
     assert e.safety_flags() == (0, 0)
 
 
