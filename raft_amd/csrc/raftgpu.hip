@@ -444,40 +444,25 @@ static bool spec_same(const DevCfg &a, const DevCfg &b) {
          a.churnDisc == b.churnDisc && a.churnRestart == b.churnRestart && a.churnCrash == b.churnCrash && a.acctBytes == b.acctBytes;
 }
 
-// Compiles and loads k_tick_spec for the engine's configuration as it is now (device of the engine current).
-static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
-  const Rtc *r = rtc();
-  if (!r) return RG_ERR_STATE;
-  if (e->specMod) { hipModuleUnload(e->specMod); e->specMod = nullptr; e->specFn = nullptr; }
-  hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, e->cfg.device));
-  std::string arch = prop.gcnArchName;                       // "gfx950:sramecc+:xnack-"
-  arch = "--offload-arch=" + arch.substr(0, arch.find(':'));
-  std::vector<std::string> opts = {arch, "-O3", "-std=c++17", "-Wno-unused-value"};
-  auto def = [&](const char *name, long long v) { opts.push_back(std::string("-DRG_SPEC_") + name + "=" + std::to_string(v)); };
-  def("P", c.P); def("EXT", ext); def("LEAN", lean); def("L", c.L); def("ROWBYTES", c.rowBytes); def("CMDOFF", c.cmdOff);
-  def("REQDROP", c.reqDrop); def("REPLYDROP", c.replyDrop); def("REPLYDELAY", c.replyDelay);
-  def("STARTPERIOD", c.startPeriod); def("STARTFIRST", c.startFirst); def("STARTMAX", c.startMax); def("STARTMODE", c.startMode);
-  def("PARTPERIOD", c.partPeriod); def("PARTJITTER", c.partJitter);
-  def("CHURNPERIOD", c.churnPeriod); def("CHURNDISC", c.churnDisc); def("CHURNRESTART", c.churnRestart); def("CHURNCRASH", c.churnCrash);
-  def("ACCTBYTES", c.acctBytes);
-  if (const char *x = getenv("RAFTGPU_SPEC_DEFS")) { std::string t = x; size_t i = 0; while (i < t.size()) { size_t j = t.find(' ', i); if (j == std::string::npos) j = t.size(); if (j > i) opts.push_back(t.substr(i, j - i)); i = j + 1; } }   // tuning aid: extra compiler options
-  // code objects already compiled in this process, by option string: engines of one configuration share the compile
+// hiprtc: the embedded sources with these options -> a code object.  Code objects already compiled in this process are
+// kept by option string, so engines of one configuration share the compile.
+static int compile_spec(const Rtc *r, const std::vector<std::string> &opts, std::vector<char> &code) {
   static std::mutex cacheMu;
   static std::unordered_map<std::string, std::vector<char>> cache;
   std::string key;
   for (auto &o : opts) { key += o; key += ' '; }
-  std::vector<char> code;
-  { std::lock_guard<std::mutex> lk(cacheMu); auto it = cache.find(key); if (it != cache.end()) code = it->second; }
-  if (code.empty()) {
+  {
+    std::lock_guard<std::mutex> lk(cacheMu);
+    auto it = cache.find(key);
+    if (it != cache.end()) { code = it->second; return RG_OK; }
+  }
   std::vector<const char *> optv;
   for (auto &o : opts) optv.push_back(o.c_str());
   const char *hdrs[] = {rg_src_abi, rg_src_state, rg_src_tick, kSpecStdint, kSpecStddef};
   const char *names[] = {"raftgpu.h", "rg_state.h", "rg_tick.h", "stdint.h", "stddef.h"};
   hiprtcProgram prog;
   if (r->create(&prog, kSpecUnit, "raftgpu_spec.hip", 5, hdrs, names) != HIPRTC_SUCCESS) return RG_ERR_HIP;
-  const hiprtcResult res = r->compile(prog, (int)optv.size(), optv.data());
-  if (res != HIPRTC_SUCCESS) {
+  if (r->compile(prog, (int)optv.size(), optv.data()) != HIPRTC_SUCCESS) {
     size_t n = 0;
     if (r->logSize(prog, &n) == HIPRTC_SUCCESS && n > 1) { std::string log(n, 0); r->log(prog, &log[0]); fprintf(stderr, "raftgpu: rg_specialize: hiprtc: %s\n", log.c_str()); }
     r->destroy(&prog);
@@ -490,7 +475,42 @@ static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
   std::lock_guard<std::mutex> lk(cacheMu);
   if (cache.size() >= 256) cache.clear();
   cache[key] = code;
+  return RG_OK;
+}
+
+// Compiles and loads k_tick_spec for configuration c of the engine (device of the engine current).
+static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
+  const Rtc *r = rtc();
+  if (!r) return RG_ERR_STATE;
+  if (e->specMod) {                                          // launches of the old kernel may still be running
+    HIPCHK(hipStreamSynchronize(e->stream));
+    hipModuleUnload(e->specMod);
+    e->specMod = nullptr; e->specFn = nullptr;
   }
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, e->cfg.device));
+  std::string arch = prop.gcnArchName;                       // "gfx950:sramecc+:xnack-"
+  arch = "--offload-arch=" + arch.substr(0, arch.find(':'));
+  std::vector<std::string> opts = {arch, "-O3", "-std=c++17", "-Wno-unused-value"};
+  auto def = [&](const char *name, long long v) { opts.push_back(std::string("-DRG_SPEC_") + name + "=" + std::to_string(v)); };
+  def("P", c.P); def("EXT", ext); def("LEAN", lean); def("L", c.L); def("ROWBYTES", c.rowBytes); def("CMDOFF", c.cmdOff);
+  def("REQDROP", c.reqDrop); def("REPLYDROP", c.replyDrop); def("REPLYDELAY", c.replyDelay);
+  def("STARTPERIOD", c.startPeriod); def("STARTFIRST", c.startFirst); def("STARTMAX", c.startMax); def("STARTMODE", c.startMode);
+  def("PARTPERIOD", c.partPeriod); def("PARTJITTER", c.partJitter);
+  def("CHURNPERIOD", c.churnPeriod); def("CHURNDISC", c.churnDisc); def("CHURNRESTART", c.churnRestart); def("CHURNCRASH", c.churnCrash);
+  def("ACCTBYTES", c.acctBytes);
+  if (const char *x = getenv("RAFTGPU_SPEC_DEFS")) {          // tuning aid: extra compiler options, blank-separated
+    const std::string t = x;
+    for (size_t i = 0; i < t.size();) {
+      size_t j = t.find(' ', i);
+      if (j == std::string::npos) j = t.size();
+      if (j > i) opts.push_back(t.substr(i, j - i));
+      i = j + 1;
+    }
+  }
+  std::vector<char> code;
+  int rc = compile_spec(r, opts, code);
+  if (rc != RG_OK) return rc;
   HIPCHK(hipModuleLoadData(&e->specMod, code.data()));
   if (hipModuleGetFunction(&e->specFn, e->specMod, "k_tick_spec") != hipSuccess) { hipModuleUnload(e->specMod); e->specMod = nullptr; e->specFn = nullptr; return RG_ERR_HIP; }
   e->specExt = ext; e->specLean = lean; e->specFor = c;
