@@ -89,7 +89,7 @@ struct rg_engine {
   std::vector<unsigned> drained;  // per (g,p): ApplyMsgs handed out by rg_drain_applied so far
   rg_apply_msg *applyRing; unsigned *applyHead; int applyCap;
   unsigned *netCfg;               // device: per-group net rates, allocated by the first rg_set_unreliable_group
-  rg_sched_op *sched; int schedN; // device: the scenario schedule
+  rg_sched_op *sched; int schedN; size_t schedCap; // device: the scenario schedule, and the room of its buffer
   std::vector<rg_sched_op> schedHost;
   std::mutex mu;
   // staging
@@ -296,7 +296,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (rc == RG_OK) rc = dalloc(e, &S.flagSummary, (size_t)2);
   if (rc != RG_OK) { free_engine(e); return rc; }
   e->drained.assign((size_t)e->G * e->P, 0);
-  e->applyCap = cfg->apply_ring_cap; e->applyRing = nullptr; e->applyHead = nullptr; e->netCfg = nullptr; e->sched = nullptr; e->schedN = 0;
+  e->applyCap = cfg->apply_ring_cap; e->applyRing = nullptr; e->applyHead = nullptr; e->netCfg = nullptr; e->sched = nullptr; e->schedN = 0; e->schedCap = 0;
   if (e->applyCap > 0) {
     rc = dalloc(e, &e->applyRing, (size_t)e->G * e->P * e->applyCap);
     if (rc == RG_OK) rc = dalloc(e, &e->applyHead, (size_t)e->nLanes);
@@ -790,6 +790,18 @@ struct TmpBuf {
   template <typename T> T *get(size_t n) { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr; p.push_back(q); return (T *)q; }
 };
 
+// ---- strided host <-> device copies of one column / word ------------------------
+static int d2h(rg_engine *e, void *dst, const void *src, size_t n) {
+  HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return RG_OK;
+}
+static int h2d(rg_engine *e, void *dst, const void *src, size_t n) {
+  HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return RG_OK;
+}
+
 // Network.Reliable / LongReordering of ONE tester config (config.go:288-294: every config owns its labrpc.Network).
 extern "C" int rg_set_unreliable_group(rg_engine *e, int32_t g, int32_t a, int32_t b, int32_t d) {
   LOCK(e);
@@ -822,8 +834,12 @@ extern "C" int rg_set_schedule(rg_engine *e, const rg_sched_op *ops, int64_t n) 
   int first = 0;                                   // ops before the current tick are never executed
   while (first < n && ops[first].tick < e->now) first++;
   if (n > 0) {
-    int rc = dalloc(e, &e->sched, (size_t)n);      // (an earlier schedule's buffer stays until rg_destroy)
-    if (rc != RG_OK) return rc;
+    if ((size_t)n > e->schedCap) {                 // (a smaller earlier buffer stays until rg_destroy)
+      const size_t cap = std::max<size_t>((size_t)n, 2 * e->schedCap);
+      int rc = dalloc(e, &e->sched, cap);
+      if (rc != RG_OK) { e->schedCap = 0; return rc; }
+      e->schedCap = cap;
+    }
     HIPCHK(hipMemcpyAsync(e->sched, ops, (size_t)n * sizeof(rg_sched_op), hipMemcpyHostToDevice, e->stream));
     e->H.sched = e->sched; e->H.schedN = (int)n; e->schedN = (int)n;
   }
@@ -838,10 +854,8 @@ extern "C" int rg_reset_groups(rg_engine *e, const int32_t *groups, int64_t n) {
   LOCK(e);
   if (n < 0 || (n > 0 && !groups)) return RG_ERR_ARG;
   if (n == 0) return RG_OK;
-  for (int64_t i = 0; i < n; i++) {
-    if (groups[i] < 0 || groups[i] >= e->G) return RG_ERR_RANGE;
-    for (int64_t j = 0; j < i; j++) if (groups[j] == groups[i]) return RG_ERR_ARG;   // one block per group: no repeats
-  }
+  for (int64_t i = 0; i < n; i++) if (groups[i] < 0 || groups[i] >= e->G) return RG_ERR_RANGE;
+  { std::vector<int> level; if (batch_levels(e, groups, 1, (size_t)n, level) > 0) return RG_ERR_ARG; }   // one block per group: no repeats
   int rc = run_derive(e);
   if (rc != RG_OK) return rc;
   TmpBuf tb;
@@ -851,27 +865,24 @@ extern "C" int rg_reset_groups(rg_engine *e, const int32_t *groups, int64_t n) {
   hipLaunchKernelGGL(k_reset_groups, dim3((unsigned)n), dim3(256), 0, e->stream, e->S, e->dc, e->PP, dg, (int)e->now);
   HIPCHK(hipGetLastError());
   const unsigned zero = 0;
-  for (int64_t i = 0; i < n; i++) {
-    if (e->netCfg) HIPCHK(hipMemcpyAsync(e->netCfg + groups[i], &zero, 4, hipMemcpyHostToDevice, e->stream));
-    if (e->applyCap > 0) {             // a new applyCh per peer: what the old peers emitted and nobody read is gone
-      unsigned heads[RG_MAX_PEERS];
-      HIPCHK(hipMemcpyAsync(heads, e->applyHead + (size_t)groups[i] * e->PP, (size_t)e->P * 4, hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipStreamSynchronize(e->stream));
-      for (int p = 0; p < e->P; p++) e->drained[(size_t)groups[i] * e->P + p] = heads[p];
+  if (e->netCfg) for (int64_t i = 0; i < n; i++) HIPCHK(hipMemcpyAsync(e->netCfg + groups[i], &zero, 4, hipMemcpyHostToDevice, e->stream));
+  if (e->applyCap > 0) {               // a new applyCh per peer: what the old peers emitted and nobody read is gone
+    std::vector<unsigned> heads;
+    if (n > 8) {                       // many groups: the whole array in one copy
+      heads.resize((size_t)e->nLanes);
+      rc = d2h(e, heads.data(), e->applyHead, heads.size() * sizeof(unsigned));
+      if (rc != RG_OK) return rc;
+      for (int64_t i = 0; i < n; i++)
+        for (int p = 0; p < e->P; p++) e->drained[(size_t)groups[i] * e->P + p] = heads[(size_t)groups[i] * e->PP + p];
+    } else {
+      heads.resize((size_t)e->PP);
+      for (int64_t i = 0; i < n; i++) {
+        rc = d2h(e, heads.data(), e->applyHead + (size_t)groups[i] * e->PP, (size_t)e->P * sizeof(unsigned));
+        if (rc != RG_OK) return rc;
+        for (int p = 0; p < e->P; p++) e->drained[(size_t)groups[i] * e->P + p] = heads[p];
+      }
     }
   }
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return RG_OK;
-}
-
-// ---- strided host <-> device copies of one column / word ------------------------
-static int d2h(rg_engine *e, void *dst, const void *src, size_t n) {
-  HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return RG_OK;
-}
-static int h2d(rg_engine *e, void *dst, const void *src, size_t n) {
-  HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return RG_OK;
 }
