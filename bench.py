@@ -16,6 +16,8 @@ collective is one all-reduce of counters and safety flags per step.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `python bench.py --gpus N` without a launcher starts its own N rank processes (one per GPU) and prints rank 0's line.
+The tick kernel is the one rg_specialize compiles for this configuration when the engine is set up (before the warm-up;
+`config.kernel_build` says which kernel ran); `--generic` runs the precompiled one.
 """
 import argparse
 import json
@@ -258,7 +260,7 @@ def main():
             "frac_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "measured_peak": HBM_MEASURED_PEAK_GBS, "frac_of_measured_peak": achieved / HBM_MEASURED_PEAK_GBS,
             "mode": ("fused: peer scalars stay in registers and LDS within a launch of %d ticks (cut into relay chunks of "
-                     "at least 1,000 ticks, at most 8, when the groups exceed what the chip holds at once)" % launch) if launch > 1
+                     "at least 1,000 ticks, at most 12, when the groups exceed what the chip holds at once)" % launch) if launch > 1
                     else "streamed: every peer's state is loaded and stored once per tick",
         },
         "safety_flags": flags, "flagged_groups": flagged_groups,

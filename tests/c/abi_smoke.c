@@ -14,6 +14,8 @@ int main(void) {
   cfg.n_groups = 64; cfg.n_peers = 3; cfg.log_cap = 64; cfg.seed = 1; cfg.apply_ring_cap = 64;   /* applyCh is read below */
   rg_engine *e = NULL;
   CHECK(rg_create(&cfg, &e));
+  { int rc = rg_specialize(e);                             /* a kernel compiled for this configuration, where hiprtc is at hand */
+    if (rc != RG_OK && rc != RG_ERR_STATE) { printf("FAIL rg_specialize: %s\n", rg_strerror(rc)); return 1; } }
   CHECK(rg_step(e, 100));                                  /* one second: an election */
   for (int k = 1; k <= 3; k++) {
     int32_t leader = -1, term = 0, is_leader = 0;
