@@ -335,6 +335,12 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
         candS = mStart < candS ? mStart : candS;
       }
       if (r.commit > r.cd(CD_APPLIED)) { cand = from; candS = from; }   // entries committed by a host call are applied at once
+      // The first connected leader takes the Starts only while its log has room: the Start that no longer fits goes to
+      // the next leader (or to nobody), whose gate it changes, so the group runs at that Start's tick and looks again.
+      if (taker && !(!LEAN && c.startMode == RG_START_ALL) && gStartSeq + (L - r.logLen) < c.startMax) {
+        const int fullAt = sTick + (L - r.logLen) * c.startPeriod;
+        candS = fullAt < candS ? fullAt : candS;
+      }
     }
     cand = G.gmin(cand);
     if (c.partPeriod > 0 && gPartNext < cand) cand = gPartNext;
@@ -431,7 +437,11 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           if (startNow && mAll && wIdx < NONE && take < due) gNextStart -= (due - take) * c.startPeriod;   // the rest goes round again
           if (cand && peer < wIdx) (void)start_cmd(r, lg, sn, peer, L, 0, gfl, w);            // full log: refused and flagged
           const bool lead = cand && peer == wIdx && take > 0;
+#ifdef RG_NO_BATCHED_STARTS
+          if (true) {
+#else
           if (wave_any(lead && r.commit >= r.logLen)) {        // a commitIndex that ran past the log: entry by entry
+#endif
             if (lead) {
               for (int j = 0; j < take; j++) {
                 u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)(gStartSeq + j));

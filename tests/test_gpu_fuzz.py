@@ -66,7 +66,13 @@ def _random_ops(rng, peers, until):
     return ops
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RAFT_FUZZ_SEEDS", "48"))))
+# seeds that once showed a difference, kept whatever RAFT_FUZZ_SEEDS says.  24193: the first connected leader's log fills
+# up while client Starts are pending, so the next leader takes the rest and ITS heartbeat gate changes (a schedule's
+# Starts had filled the first one's log early)
+REGRESSIONS = [24193]
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("RAFT_FUZZ_SEEDS", "48")))) + REGRESSIONS)
 def test_random_schedule(seed):
     from oracle.binding import OracleEngine
     from raft_amd import Engine
