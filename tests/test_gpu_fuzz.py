@@ -72,7 +72,10 @@ def _random_ops(rng, peers, until):
 REGRESSIONS = [24193]
 
 
-@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("RAFT_FUZZ_SEEDS", "48")))) + REGRESSIONS)
+_ENV = __import__("os").environ
+
+
+@pytest.mark.parametrize("seed", list(range(int(_ENV.get("RAFT_FUZZ_FIRST", "0")), int(_ENV.get("RAFT_FUZZ_SEEDS", "48")))) + REGRESSIONS)
 def test_random_schedule(seed):
     from oracle.binding import OracleEngine
     from raft_amd import Engine
