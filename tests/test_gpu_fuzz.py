@@ -77,12 +77,30 @@ _ENV = __import__("os").environ
 
 @pytest.mark.parametrize("seed", list(range(int(_ENV.get("RAFT_FUZZ_FIRST", "0")), int(_ENV.get("RAFT_FUZZ_SEEDS", "48")))) + REGRESSIONS)
 def test_random_schedule(seed):
+    _run(seed)
+
+
+@pytest.mark.parametrize("seed", range(int(_ENV.get("RAFT_FUZZ_TINY_FIRST", "0")), int(_ENV.get("RAFT_FUZZ_TINY", "24"))))
+def test_random_schedule_tiny_logs(seed):
+    """The same with logs of 8 to 24 entries, Starts every tick or two and a schedule most of the time: logs fill up,
+    Starts are refused and move on to the next leader, commitIndex runs past truncated logs."""
+    def tweak(rng, kw):
+        kw["log_cap"] = rng.choice([8, 12, 24])
+        kw.update(start_period=rng.choice([1, 1, 2]), start_first_tick=rng.choice([0, 30]), start_max=kw["log_cap"] - 1,
+                  start_mode=rng.choice([_abi.START_ONE, _abi.START_ONE, _abi.START_ALL]))
+        kw.pop("apply_ring_cap", None)
+        return 0.7
+    _run(500000 + seed, tweak)
+
+
+def _run(seed, tweak=None):
     from oracle.binding import OracleEngine
     from raft_amd import Engine
     rng = random.Random(1000 + seed)
     kw = _random_config(rng)
+    p_sched = tweak(rng, kw) if tweak else 0.35
     o, e = OracleEngine(_abi.make_config(**kw)), Engine(_abi.make_config(**kw))
-    if rng.random() < 0.35:
+    if rng.random() < p_sched:
         ops = _random_ops(rng, kw["n_peers"], 1500)
         o.set_schedule(ops)
         e.set_schedule(ops)
