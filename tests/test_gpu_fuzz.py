@@ -100,6 +100,8 @@ def _run(seed, tweak=None):
     kw = _random_config(rng)
     p_sched = tweak(rng, kw) if tweak else 0.35
     o, e = OracleEngine(_abi.make_config(**kw)), Engine(_abi.make_config(**kw))
+    if random.Random(77 + seed).random() < float(_ENV.get("RAFT_FUZZ_SPECIALIZE", "0.06")):   # (its own stream: the case stays the same)
+        e.specialize()                                  # some cases run on a kernel compiled for their configuration
     if rng.random() < p_sched:
         ops = _random_ops(rng, kw["n_peers"], 1500)
         o.set_schedule(ops)
