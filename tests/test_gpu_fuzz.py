@@ -93,7 +93,19 @@ def test_random_schedule_tiny_logs(seed):
     _run(500000 + seed, tweak)
 
 
-def _run(seed, tweak=None):
+@pytest.mark.parametrize("seed", range(int(_ENV.get("RAFT_FUZZ_WIDE_FIRST", "0")), int(_ENV.get("RAFT_FUZZ_WIDE", "6"))))
+def test_random_schedule_many_groups(seed):
+    """A few hundred to a few thousand groups: several blocks, thin waves in the last batch, the real packing rules."""
+    def tweak(rng, kw):
+        kw["n_groups"] = rng.choice([300, 700, 1500, 4100])
+        kw["log_cap"] = rng.choice([32, 96])
+        if "start_max" in kw:
+            kw["start_max"] = kw["log_cap"] - 1
+        return 0.35
+    _run(900000 + seed, tweak, until=700)
+
+
+def _run(seed, tweak=None, until=1500):
     from oracle.binding import OracleEngine
     from raft_amd import Engine
     rng = random.Random(1000 + seed)
@@ -103,11 +115,11 @@ def _run(seed, tweak=None):
     if random.Random(77 + seed).random() < float(_ENV.get("RAFT_FUZZ_SPECIALIZE", "0.06")):   # (its own stream: the case stays the same)
         e.specialize()                                  # some cases run on a kernel compiled for their configuration
     if rng.random() < p_sched:
-        ops = _random_ops(rng, kw["n_peers"], 1500)
+        ops = _random_ops(rng, kw["n_peers"], until)
         o.set_schedule(ops)
         e.set_schedule(ops)
     t = 0
-    while t < 1500:
+    while t < until:
         n = rng.choice([1, 1, 2, 3, 5, 8, 13, 50, 200, 600])
         o.step(n)
         e.step(n)
