@@ -620,6 +620,47 @@ def election_loop_sleeps_with_its_slack(mk):
     return e
 
 
+def candidate_rounds_on_a_lossy_net(mk):
+    """raft.go:566-660 with labrpc.go:216-307: six RequestVote rounds of one candidate on a net that drops 40 % of the
+    requests and 40 % of the replies, every Call worked out from its hash: a peer adopts the candidate's term exactly
+    when the request reached it, a failed round ends in a sleep of 50 ms + slack after the round's waits, and the round
+    that wins sets heartbeatTimer to the end of its waits."""
+    m32 = 0xFFFFFFFF
+
+    def slack(key, p, now):
+        h = ((key & m32) ^ ((p * 0x9E3779B1) & m32) ^ ((now * 0x85EBCA6B) & m32)) & m32
+        h ^= h >> 16
+        h = (h * 0x7FEB352D) & m32
+        h ^= h >> 15
+        h = (h * 0x846CA68B) & m32
+        h ^= h >> 16
+        return h >> 30
+
+    seed = 15
+    e = mk(n_groups=1, n_peers=5, log_cap=16, seed=seed, req_drop_permille=400, reply_drop_permille=400)
+    key = _sm64(_sm64(seed))
+    rounds = 0
+    for t in range(200):
+        q, state, terms = int(e.read("roundseq")[0, 0]), int(e.read("state")[0, 0]), e.read("term")[0].copy()
+        e.step(1)
+        if int(e.read("roundseq")[0, 0]) == q:
+            continue
+        assert state == 1 and int(e.read("roundseq")[0, 0]) == q + 1      # a candidate's round (peer 0: timeout 0 at boot, raft.go:545)
+        now, cost, term = 10 * t, 0, int(e.read("term")[0, 0])
+        for j in range(1, 5):
+            kind, ms = _net_call(seed, 0, 0, j, q, 400, 400, 0)
+            cost += ms
+            assert int(e.read("term")[0, j]) == (term if kind != "lost" else int(terms[j]))
+        rounds += 1
+        if int(e.read("state")[0, 0]) == 2:
+            assert int(e.read("hbtimer")[0, 0]) == now + cost                       # raft.go:645-651
+            break
+        assert int(e.read("elnext")[0, 0]) == now + cost + 50 + slack(key, 0, now)  # raft.go:660 after the round's waits
+        assert int(e.read("term")[0, 0]) == 1                                       # a failed round is retried in the same term
+    assert rounds == 6 and e.get_state(0, 0) == (1, True)
+    return e
+
+
 CASES = {f.__name__: f for f in (
     boot_and_three_starts, conflict_reply, append_truncates_unconditionally, leader_backoff, commit_rule,
     vote_compares_commit_index, restore_repersists_one_entry, start_on_isolated_leader, stop_rule,
@@ -628,4 +669,4 @@ CASES = {f.__name__: f for f in (
     failed_candidate_retries_same_term, rng_draw_points, apply_stream_keeps_what_was_applied,
     apply_ring_overrun_is_reported, vote_test_reads_the_voters_own_entry, a_failed_call_costs_its_short_delay,
     partitions_and_commands_follow_their_hashes, churn_follows_its_hashes,
-    election_loop_sleeps_with_its_slack)}
+    election_loop_sleeps_with_its_slack, candidate_rounds_on_a_lossy_net)}
