@@ -111,6 +111,9 @@ def _run(seed, tweak=None, until=1500):
     rng = random.Random(1000 + seed)
     kw = _random_config(rng)
     p_sched = tweak(rng, kw) if tweak else 0.35
+    if _ENV.get("RAFT_FUZZ_EXT"):                       # every case on the extended instantiation: byte accounting and an apply ring
+        kw["account_bytes"] = 1
+        kw.setdefault("apply_ring_cap", 64)
     o, e = OracleEngine(_abi.make_config(**kw)), Engine(_abi.make_config(**kw))
     if random.Random(77 + seed).random() < float(_ENV.get("RAFT_FUZZ_SPECIALIZE", "0.06")):   # (its own stream: the case stays the same)
         e.specialize()                                  # some cases run on a kernel compiled for their configuration
