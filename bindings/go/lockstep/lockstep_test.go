@@ -58,6 +58,7 @@ const (
 	streamCmd      = 3
 	streamPart     = 4
 	streamChurn    = 5
+	streamSched    = 6 // scenario schedules (rg_set_schedule) are not among this driver's cases; listed to keep the numbering whole
 )
 
 var lsCounterNames = []string{"group_ticks", "rpc_sent", "rpc_delivered", "rpc_replied", "rv_rounds", "elections_won",
@@ -237,7 +238,14 @@ func permilleOf(field16 uint32) int { return int((field16 * 1000) >> 16) }
 func (e *lsEngine) netOutcome(g *lsGroup, s, j int, seq uint32) (out int, cost int64, wire bool) {
 	a, b := g.peers[s], g.peers[j]
 	cost = lsRPCWait
+	// (every dead peer of this driver died by crash1, whose DeleteServer takes it off the net, config.go:99-127; a
+	// peer that was only Kill()ed would still be served -- that verb is not among the driver's cases)
 	if !(a.connected && b.connected && a.side == b.side) || b.rf.killed() {
+		h := streamHash(g.key, streamNet, (uint32(s)<<8)|uint32(j), seq)
+		ms := int64(((h >> 32) * 7000) >> 32) // labrpc.go:296: Call returns false after 0..6999 ms
+		if ms < cost {
+			cost = ms
+		}
 		return netLost, cost, false
 	}
 	c := &e.cfg

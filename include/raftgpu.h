@@ -9,7 +9,7 @@
  *   Make        src/raft/raft.go:700   -> rg_create / rg_restart
  *   Start       src/raft/raft.go:344   -> rg_start / rg_start_batch
  *   GetState    src/raft/raft.go:90    -> rg_get_state
- *   Kill        src/raft/raft.go:377   -> rg_crash
+ *   Kill        src/raft/raft.go:377   -> rg_kill (the tester's crash1, config.go:99-127 -> rg_crash)
  *   ApplyMsg    src/raft/raft.go:42    -> rg_drain_applied
  *   persist / readPersist  src/raft/raft.go:107,129 and the Persister of
  *               src/raft/persister.go:20-70 -> rg_snapshot_export/import
@@ -72,6 +72,7 @@ extern "C" {
 #define RG_FLAG_APPLY_ORDER         0x10u /* apply skipped an index (src/raft/config.go:184,191-193)        */
 #define RG_FLAG_REF_PANIC           0x20u /* state in which the reference would index past len(logs)        */
 #define RG_FLAG_LOG_OVERFLOW        0x40u /* a Start was refused because the fixed log capacity is full     */
+#define RG_N_FLAG_BITS 7
 
 /* ---- counters (uint64 each) --------------------------------------------- */
 enum {
@@ -97,12 +98,24 @@ enum {
   RG_N_COUNTERS
 };
 
+/* ---- safety summary (uint64 each): what rg_safety_summary and rg_allreduce_summary report ------------------ */
+enum {
+  RG_S_BIT_GROUPS = 0,        /* [RG_N_FLAG_BITS] groups whose flag word has bit b set                          */
+  RG_S_FLAGGED_GROUPS = RG_N_FLAG_BITS, /* groups with any flag                                                  */
+  RG_S_ROUNDS_FLAGGED,        /* RequestVote + AppendEntries rounds sent by peers of flagged groups ...          */
+  RG_S_ROUNDS_ALL,            /* ... and of all groups (a round is up to n_peers - 1 Calls)                      */
+  RG_S_RECORDED_FLAGGED,      /* highest index the tester recorded as applied (config.go:170-194), summed over flagged groups ... */
+  RG_S_RECORDED_ALL,          /* ... and over all groups                                                         */
+  RG_N_SUMMARY
+};
+
 /* ---- state fields for rg_read_state / rg_write_state -------------------- *
  * Host layout: per-peer fields int32 [n_groups][n_peers]; per-group fields
  * int32 [n_groups]; matrices int32 [n_groups][n_peers(owner)][n_peers];
  * logs [n_groups][n_peers][log_cap] (int32 terms, uint64 commands).
  * TIMER, HBTIMER, ELNEXT, MONNEXT, TIMEOUT are in ms of simulated time
- * (tick x 10), PARTNEXT in ticks.                                          */
+ * (tick x 10), PARTNEXT in ticks.  DEAD: 0 alive, 1 crashed (crash1: its server is
+ * gone from the net), 2 killed (Kill(): dead flag only, Calls to it still return). */
 enum {
   RG_F_TERM = 0, RG_F_VOTE, RG_F_STATE, RG_F_COMMIT, RG_F_APPLIED, RG_F_LOGLEN,
   RG_F_TIMER, RG_F_TIMEOUT, RG_F_HBTIMER, RG_F_STOP, RG_F_CNT, RG_F_DEAD,
@@ -233,13 +246,20 @@ int rg_start_batch(rg_engine *e, rg_start_req *reqs, int64_t n);
 int rg_get_state(rg_engine *e, int32_t group, int32_t peer, int32_t *term, int32_t *is_leader);
 
 /* Harness verbs (config.go:235-278, 99-127, 136-215).  rg_crash = crash1:
- * disconnect, drop volatile state, keep the snapshot arrays.  rg_restart =
- * start1: crash1, then Make + readPersist from the snapshot arrays; the peer
- * stays disconnected until rg_set_connected, as in the harness. */
+ * disconnect, delete the server from the net, drop volatile state, keep the
+ * snapshot arrays.  rg_restart = start1: crash1, then Make + readPersist from
+ * the snapshot arrays; the peer stays disconnected until rg_set_connected, as
+ * in the harness. */
 int rg_set_connected(rg_engine *e, int32_t group, int32_t peer, int32_t connected);
 int rg_set_side(rg_engine *e, int32_t group, int32_t peer, int32_t side);
 int rg_crash(rg_engine *e, int32_t group, int32_t peer);
 int rg_restart(rg_engine *e, int32_t group, int32_t peer);
+/* Kill (raft.go:377-380): the dead flag and nothing else.  The peer's loops end (:395, :548, :674), GetState and
+ * Start answer not-leader, its handlers return at once (:203, :273) -- but it stays connected and its server stays
+ * registered, so a Call to it returns TRUE with the reply as the caller initialised it: a leader counts the peer
+ * active (:476-477), reads Success = false with ConflictTerm 0 and backs nextIndex off to 1 (:493-499); a candidate
+ * counts it active without a vote.  No effect on a peer that is already dead.  rg_restart brings it back. */
+int rg_kill(rg_engine *e, int32_t group, int32_t peer);
 /* Network.Reliable / LongReordering (labrpc.go:169-181), all groups. */
 int rg_set_unreliable(rg_engine *e, int32_t req_drop_permille,
                       int32_t reply_drop_permille, int32_t reply_delay_permille);
@@ -277,6 +297,7 @@ enum {
   RG_OP_PICK_OTHER,        /* a: register := the first connected live peer after selector b, in cyclic order, or none */
   RG_OP_RESTART_IF_FEWER,  /* a: selector, b: n; if that peer is dead and fewer than n peers are alive: start1 + connect  test_test.go:718-725 */
   RG_OP_CONNECT_IF_FEWER,  /* a: selector, b: n; if that peer is disconnected and fewer than n peers are connected: connect  test_test.go:805-811 */
+  RG_OP_KILL,              /* a: selector; rf.Kill(): dead flag only, the peer stays on the net          raft.go:377-380   */
   RG_OP_END
 };
 typedef struct rg_sched_op { int32_t tick, op, a, b; } rg_sched_op;
@@ -333,10 +354,31 @@ int rg_rpc_bytes(rg_engine *e, int64_t command_bytes, uint64_t *total);   /* RG_
 int rg_safety_check(rg_engine *e);
 /* out[0] = OR of all group flag words, out[1] = number of flagged groups. */
 int rg_safety_flags(rg_engine *e, uint32_t *out /* 2 */);
+/* Flagged groups per flag bit and the share of the run's work they did (RG_S_* above), this engine's groups. */
+int rg_safety_summary(rg_engine *e, uint64_t *out /* RG_N_SUMMARY */);
 /* Device addresses of the counter block (RG_N_COUNTERS x uint64) and of the
- * flag summary (2 x uint32, refreshed by rg_safety_flags) for collectives
- * that reduce them in place across GPUs. */
+ * flag summary (2 x uint32, refreshed by rg_safety_flags) for callers that
+ * run their own collectives. */
 int rg_device_buffers(rg_engine *e, void **counters_dev, void **flag_summary_dev);
+
+/* ---- the one cross-GPU exchange of the path: counters and safety summary, summed over the ranks ----------------
+ * No counterpart in the reference (one process, one group per test).  Groups are sharded over GPUs by global id and
+ * never exchange anything; what a multi-GPU job reports is the sum of every rank's counters (RG_C_*) and safety
+ * summary (RG_S_*: groups per flag bit -- a bit is set somewhere in the job iff its count is non-zero).  The engine
+ * packs the RG_N_COUNTERS + RG_N_SUMMARY words into one device buffer and reduces it in place with ONE ncclAllReduce
+ * (uint64, sum) on its stream -- RCCL over xGMI, 248 bytes: latency-bound -- then copies the result out.  librccl.so
+ * is loaded when first needed (RG_ERR_STATE if it cannot be); the library does not link against it.
+ *   rg_comm_unique_id: ncclGetUniqueId on one rank; the caller carries the RG_COMM_ID_BYTES to the other ranks.
+ *   rg_comm_init: ncclCommInitRank on the engine's device; collective over all n_ranks.  n_ranks == 1 needs no id.
+ *   rg_allreduce_summary: nccl_comm = a caller-made ncclComm_t for the engine's device, or NULL for the communicator
+ *     of rg_comm_init; with neither (a single-GPU job) the call just reports this engine's own words.  Either
+ *     output pointer may be NULL.  Collective: every rank calls it once per reporting boundary, never per tick. */
+#define RG_COMM_ID_BYTES 128
+int rg_comm_unique_id(void *id_out);
+int rg_comm_init(rg_engine *e, int32_t rank, int32_t n_ranks, const void *id);
+int rg_comm_destroy(rg_engine *e);
+int rg_allreduce_summary(rg_engine *e, void *nccl_comm, uint64_t *counters_out /* RG_N_COUNTERS */,
+                         uint64_t *summary_out /* RG_N_SUMMARY */);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,8 @@ def load(path=None):
         "ro_start": ([vp, i32, i32, C.c_uint64, P(i32), P(i32), P(i32)], C.c_int),
         "ro_get_state": ([vp, i32, i32, P(i32), P(i32)], C.c_int),
         "ro_set_connected": ([vp, i32, i32, i32], C.c_int), "ro_set_side": ([vp, i32, i32, i32], C.c_int),
-        "ro_crash": ([vp, i32, i32], C.c_int), "ro_restart": ([vp, i32, i32], C.c_int),
+        "ro_crash": ([vp, i32, i32], C.c_int), "ro_restart": ([vp, i32, i32], C.c_int), "ro_kill": ([vp, i32, i32], C.c_int),
+        "ro_set_repaired_rules": ([vp, C.c_int], None), "ro_safety_summary": ([vp, P(C.c_uint64)], C.c_int),
         "ro_set_unreliable": ([vp, i32, i32, i32], C.c_int),
         "ro_set_unreliable_group": ([vp, i32, i32, i32, i32], C.c_int),
         "ro_reset_groups": ([vp, P(i32), i64], C.c_int),
@@ -101,6 +102,11 @@ class OracleEngine(EngineBase):
 
     def set_full_persist(self, on):
         self._lib.ro_set_full_persist(self._h, 1 if on else 0)
+
+    def set_repaired_rules(self, mask=7):
+        """TEST-ONLY: repair the reference's rules (bit 1: vote on the last log entry, 2: persist the whole log,
+        4: a demoting handler clears `restart`), to tell its own violations from a model defect."""
+        self._lib.ro_set_repaired_rules(self._h, int(mask))
 
     def step_mt(self, n_ticks, n_threads):
         self._check(self._lib.ro_step_mt(self._h, n_ticks, n_threads), "step_mt")

@@ -78,6 +78,7 @@ struct ro_engine {
   int P, L, G;
   int64_t now;
   int fullPersist;
+  int repaired;          /* RO_REPAIR_* bits: test-only departures from the reference's rules (ro_set_repaired_rules) */
   rg_sched_op *sched; int schedN;
   group_t *groups;
   uint64_t counters[RG_N_COUNTERS];
@@ -124,7 +125,7 @@ static int32_t sleep_slack(const group_t *g, int p, int32_t now) {
 /* ---------------- persist / readPersist --------------------------------- */
 /* persist(), raft.go:107-123: currentTerm, voteFor, logs[0:commitIndex+1]. */
 static void persist(ro_engine *e, ctr_t *c, peer_t *rf) {
-  int n = rf->commit + 1;
+  int n = (e->repaired & RO_REPAIR_PERSIST_LOG) ? rf->logLen : rf->commit + 1;
   if (n > e->L) n = e->L;
   rf->snapTerm = rf->term;
   rf->snapVote = rf->vote;
@@ -161,7 +162,7 @@ static void make_peer(ro_engine *e, ctr_t *c, group_t *g, int p, int32_t now) {
     if (n > rf->snapSync) rf->snapSync = n;
     rf->logLen = n;
     persist(e, c, rf);                              /* :147, commitIndex is still 0 */
-    rf->commit = rf->logLen - 1;                    /* :148 */
+    if (!(e->repaired & RO_REPAIR_PERSIST_LOG)) rf->commit = rf->logLen - 1;   /* :148 */
   }
   rf->monAlive = 0; rf->first = 0; rf->monNext = 0;
   rf->restart = 0;
@@ -184,9 +185,12 @@ static void request_vote(ro_engine *e, ctr_t *c, peer_t *rf, int32_t now, const 
     if (a->term > rf->term) { rf->term = a->term; rf->vote = -1; persist(e, c, rf); }
     r->term = rf->term;
     rf->state = RG_FOLLOWER;                                      /* :216 */
-    int32_t myLastTerm = rf->logTerm[rf->commit];                 /* logs[commitIndex].Term */
+    if (e->repaired & RO_REPAIR_RESTART) rf->restart = 0;
+    int32_t myLastIndex = rf->commit;
+    if (e->repaired & RO_REPAIR_VOTE_LAST_LOG) myLastIndex = rf->logLen - 1;
+    int32_t myLastTerm = rf->logTerm[myLastIndex];                /* logs[commitIndex].Term */
     if ((rf->vote == -1 || rf->vote == a->candidate) &&
-        (a->last_log_term > myLastTerm || (a->last_log_term == myLastTerm && a->last_log_index >= rf->commit))) {
+        (a->last_log_term > myLastTerm || (a->last_log_term == myLastTerm && a->last_log_index >= myLastIndex))) {
       r->granted = 1;
       rf->vote = a->candidate;
       persist(e, c, rf);
@@ -206,6 +210,7 @@ static void append_entries(ro_engine *e, ctr_t *c, group_t *g, peer_t *rf, int32
     r->term = rf->term;
   } else {
     rf->state = RG_FOLLOWER;
+    if (e->repaired & RO_REPAIR_RESTART) rf->restart = 0;
     rf->vote = a->leader;                                         /* :281 */
     if (rf->term < a->term) { rf->term = a->term; persist(e, c, rf); }
     r->term = rf->term;
@@ -245,14 +250,24 @@ enum { NET_LOST = 0, NET_REPLY_LOST = 1, NET_OK = 2 };
 /* *cost: how long the sender's select (raft.go:469-474, 605-609) waits for this Call: until Call returns, true
  * or false, or 25 ms, whichever comes first.  A request or reply the net drops makes Call return false right
  * after the net's short delay (labrpc.go:226-229, 273-275); a Call to an unreachable peer returns false after
- * 0..6999 ms (labrpc.go:290-305: the whole 25 ms here), a long-reordered reply comes after 200 ms or more. */
+ * 0..6999 ms (labrpc.go:290-305; the tester sets longDelays, config.go:82), i.e. before the 25 ms are over in 25
+ * of 7000 Calls; a long-reordered reply comes after 200 ms or more.
+ * A peer is unreachable when an end is disabled, the sides differ, or its server was deleted (crash1,
+ * config.go:99-127: dead == 1).  A peer that was only Kill()ed (raft.go:377-380: dead == 2) still has its server
+ * registered: the Call is delivered, the handler returns at once (raft.go:203,273) and Call returns true with
+ * the reply untouched. */
 static inline int32_t permille_of(uint32_t field16) { return (int32_t)((field16 * 1000u) >> 16); }
 
 static int net_outcome(const ro_engine *e, const group_t *g, int s, int j, uint32_t seq, int32_t *cost, int *wire) {
   const peer_t *a = &g->peer[s], *b = &g->peer[j];
   *cost = RG_RPC_WAIT_MS;
   *wire = 0;                      /* does the reply travel (and count its bytes, labrpc.go:286-290), in time or not */
-  if (!(a->connected && b->connected && a->side == b->side) || b->dead) return NET_LOST;
+  if (!(a->connected && b->connected && a->side == b->side) || b->dead == 1) {
+    uint64_t h = stream_hash(g->key, STREAM_NET, ((uint32_t)s << 8) | (uint32_t)j, seq);
+    int32_t ms = (int32_t)(((h >> 32) * 7000ull) >> 32);            /* labrpc.go:296, 0..6999 */
+    if (ms < RG_RPC_WAIT_MS) *cost = ms;
+    return NET_LOST;
+  }
   const int32_t reqDrop = g->netOwn ? g->reqDrop : e->cfg.req_drop_permille;
   const int32_t replyDrop = g->netOwn ? g->replyDrop : e->cfg.reply_drop_permille;
   const int32_t replyDelay = g->netOwn ? g->replyDelay : e->cfg.reply_delay_permille;
@@ -309,6 +324,7 @@ static void election_step(ro_engine *e, ctr_t *c, group_t *g, int me, int32_t no
     rf->vote = me;
     persist(e, c, rf);
     rg_vote_args args = { rf->term, me, rf->commit, rf->logTerm[rf->commit] };   /* :579-584 */
+    if (e->repaired & RO_REPAIR_VOTE_LAST_LOG) { args.last_log_index = rf->logLen - 1; args.last_log_term = rf->logTerm[rf->logLen - 1]; }
     rg_vote_reply reply = { rf->term, 0 };
     persist(e, c, rf);
     c->c[RG_C_RV_ROUNDS]++;
@@ -520,6 +536,12 @@ static void crash1(group_t *g, int p) {
   g->peer[p].connected = 0;
   g->peer[p].dead = 1;
 }
+/* rf.Kill(), raft.go:377-380: the dead flag alone.  The peer's loops exit (:395,:548,:674), its handlers return at
+ * once (:203,:273); its server stays registered with the net, so Calls to it still come back true (dead == 2).
+ * A peer whose server was already deleted stays that way. */
+static void kill1(group_t *g, int p) {
+  if (!g->peer[p].dead) g->peer[p].dead = 2;
+}
 static void start1(ro_engine *e, ctr_t *c, group_t *g, int p, int32_t now) {
   crash1(g, p);
   make_peer(e, c, g, p, now);
@@ -545,6 +567,7 @@ static void sched_op(ro_engine *e, ctr_t *c, group_t *g, const rg_sched_op *op, 
   case RG_OP_CONNECT:    for (int p = 0; p < P; p++) if (tgt == p || tgt == -2) g->peer[p].connected = 1; break;   /* config.go:235-256 */
   case RG_OP_DISCONNECT: for (int p = 0; p < P; p++) if (tgt == p || tgt == -2) g->peer[p].connected = 0; break;   /* config.go:258-278 */
   case RG_OP_CRASH:      for (int p = 0; p < P; p++) if (tgt == p || tgt == -2) crash1(g, p); break;
+  case RG_OP_KILL:       for (int p = 0; p < P; p++) if (tgt == p || tgt == -2) kill1(g, p); break;                     /* raft.go:377-380 */
   case RG_OP_RESTART:    for (int p = 0; p < P; p++) if (tgt == p || tgt == -2) start1(e, c, g, p, tick * RG_TICK_MS); break;
   case RG_OP_RESTART_IF_FEWER: {                                            /* test_test.go:718-725 */
     int alive = 0;
@@ -777,6 +800,7 @@ void ro_destroy(ro_engine *e) {
 }
 
 void ro_set_full_persist(ro_engine *e, int on) { e->fullPersist = on; }
+void ro_set_repaired_rules(ro_engine *e, int mask) { e->repaired = mask; }
 int64_t ro_now(ro_engine *e) { return e->now; }
 
 static void add_counters(ro_engine *e, const ctr_t *c) { for (int i = 0; i < RG_N_COUNTERS; i++) e->counters[i] += c->c[i]; }
@@ -845,6 +869,7 @@ int ro_get_state(ro_engine *e, int32_t g, int32_t p, int32_t *term, int32_t *lea
 int ro_set_connected(ro_engine *e, int32_t g, int32_t p, int32_t on) { CHECK_GP(e, g, p); e->groups[g].peer[p].connected = on ? 1 : 0; return RG_OK; }
 int ro_set_side(ro_engine *e, int32_t g, int32_t p, int32_t side) { CHECK_GP(e, g, p); e->groups[g].peer[p].side = side & 1; return RG_OK; }
 int ro_crash(ro_engine *e, int32_t g, int32_t p) { CHECK_GP(e, g, p); crash1(&e->groups[g], p); return RG_OK; }
+int ro_kill(ro_engine *e, int32_t g, int32_t p) { CHECK_GP(e, g, p); kill1(&e->groups[g], p); return RG_OK; }
 int ro_restart(ro_engine *e, int32_t g, int32_t p) {
   CHECK_GP(e, g, p);
   ctr_t c; memset(&c, 0, sizeof c);
@@ -1098,6 +1123,23 @@ int ro_safety_flags(ro_engine *e, uint32_t *out) {
   uint32_t o = 0, n = 0;
   for (int g = 0; g < e->G; g++) { o |= e->groups[g].flags; n += e->groups[g].flags != 0; }
   out[0] = o; out[1] = n;
+  return RG_OK;
+}
+
+/* rg_safety_summary's words: groups per flag bit, flagged groups, and how much of the run's work the flagged
+ * groups did (rounds their peers sent; highest index their testers recorded). */
+int ro_safety_summary(ro_engine *e, uint64_t *out) {
+  if (!e || !out) return RG_ERR_ARG;
+  memset(out, 0, sizeof(uint64_t) * RG_N_SUMMARY);
+  for (int g = 0; g < e->G; g++) {
+    const group_t *gr = &e->groups[g];
+    uint64_t rounds = 0;
+    for (int p = 0; p < e->P; p++) rounds += gr->peer[p].roundSeq;
+    for (int b = 0; b < RG_N_FLAG_BITS; b++) if ((gr->flags >> b) & 1u) out[RG_S_BIT_GROUPS + b]++;
+    out[RG_S_ROUNDS_ALL] += rounds;
+    out[RG_S_RECORDED_ALL] += (uint64_t)gr->recMax;
+    if (gr->flags) { out[RG_S_FLAGGED_GROUPS]++; out[RG_S_ROUNDS_FLAGGED] += rounds; out[RG_S_RECORDED_FLAGGED] += (uint64_t)gr->recMax; }
+  }
   return RG_OK;
 }
 

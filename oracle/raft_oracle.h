@@ -33,6 +33,19 @@ void ro_reset(ro_engine *e);
  * reference re-encodes it (raft.go:116-122), instead of only the new part.
  * Results are identical; only the cost differs. */
 void ro_set_full_persist(ro_engine *e, int on);
+/* TEST-ONLY departures from the reference's rules, to tell violations the reference's own rules cause from
+ * violations a defect of the lockstep model would cause: with all three set, a schedule must end without a
+ * safety flag.  Never set by parity tests (the HIP engine has no such switch).
+ *   VOTE_LAST_LOG: RequestVote's up-to-date test and the candidate's LastLog* use the last log entry, not
+ *                  commitIndex (raft.go:218-219, 582-583);
+ *   PERSIST_LOG:   persist() stores the whole log, not logs[0:commitIndex+1] (raft.go:120), and readPersist
+ *                  leaves commitIndex at 0 instead of len-1 (raft.go:148);
+ *   RESTART:       a handler that makes the peer a follower clears the election loop's `restart`, so a round
+ *                  of a later candidacy increments the term (raft.go:569-573, 660). */
+#define RO_REPAIR_VOTE_LAST_LOG 1
+#define RO_REPAIR_PERSIST_LOG   2
+#define RO_REPAIR_RESTART       4
+void ro_set_repaired_rules(ro_engine *e, int mask);
 
 int ro_step(ro_engine *e, int32_t n_ticks);
 int ro_step_mt(ro_engine *e, int32_t n_ticks, int32_t n_threads);
@@ -43,6 +56,7 @@ int ro_get_state(ro_engine *e, int32_t g, int32_t p, int32_t *term, int32_t *is_
 int ro_set_connected(ro_engine *e, int32_t g, int32_t p, int32_t on);
 int ro_set_side(ro_engine *e, int32_t g, int32_t p, int32_t side);
 int ro_crash(ro_engine *e, int32_t g, int32_t p);
+int ro_kill(ro_engine *e, int32_t g, int32_t p);
 int ro_restart(ro_engine *e, int32_t g, int32_t p);
 int ro_set_unreliable(ro_engine *e, int32_t req_drop, int32_t reply_drop, int32_t reply_delay);
 int ro_set_unreliable_group(ro_engine *e, int32_t g, int32_t req_drop, int32_t reply_drop, int32_t reply_delay);
@@ -62,6 +76,7 @@ int ro_counters(ro_engine *e, uint64_t *out);
 int ro_rpc_bytes(ro_engine *e, int64_t command_bytes, uint64_t *total);
 int ro_safety_check(ro_engine *e);
 int ro_safety_flags(ro_engine *e, uint32_t *out);
+int ro_safety_summary(ro_engine *e, uint64_t *out /* RG_N_SUMMARY */);
 
 int ro_snapshot_export(ro_engine *e, int32_t g, int32_t p, void *buf, int64_t cap, int64_t *size_out);
 int ro_snapshot_import(ro_engine *e, int32_t g, int32_t p, const void *buf, int64_t size);

@@ -32,6 +32,12 @@ COUNTERS = [
     "rpc_fixed_bytes", "ae_entries_sent",
 ]
 N_COUNTERS = len(COUNTERS)
+N_FLAG_BITS = 7
+FLAG_NAMES = ["election_safety", "log_matching", "leader_completeness", "state_machine", "apply_order", "ref_panic", "log_overflow"]
+# rg_safety_summary / rg_allreduce_summary words (RG_S_*)
+SUMMARY = ["groups_" + n for n in FLAG_NAMES] + ["flagged_groups", "rounds_flagged", "rounds_all", "recorded_flagged", "recorded_all"]
+N_SUMMARY = len(SUMMARY)
+COMM_ID_BYTES = 128
 
 # field id -> (name, kind); kinds: p32 [G][P] i32, p64 [G][P] u64, m32 [G][P][P],
 # l32 [G][P][L] i32, l64 [G][P][L] u64, g32 [G] i32, r64 [G][L] u64
@@ -53,7 +59,7 @@ START_ONE, START_ALL = 0, 1
 
 # scenario schedule ops and selectors
 (OP_CONNECT, OP_DISCONNECT, OP_CRASH, OP_RESTART, OP_START, OP_START_ANY, OP_START_ALL, OP_PICK_LEADER, OP_PICK_RANDOM,
- OP_PICK_OTHER, OP_RESTART_IF_FEWER, OP_CONNECT_IF_FEWER) = range(1, 13)
+ OP_PICK_OTHER, OP_RESTART_IF_FEWER, OP_CONNECT_IF_FEWER, OP_KILL) = range(1, 14)
 SEL_ALL = 0x80
 
 
@@ -122,10 +128,10 @@ def make_config(**kw):
 EXPORTS = [
     "rg_device_count", "rg_version", "rg_strerror", "rg_create", "rg_destroy", "rg_reset", "rg_set_stream",
     "rg_step", "rg_step_noalloc", "rg_specialize", "rg_sync", "rg_now", "rg_step_time_ms", "rg_start", "rg_start_batch", "rg_get_state",
-    "rg_set_connected", "rg_set_side", "rg_crash", "rg_restart", "rg_set_unreliable", "rg_set_unreliable_group", "rg_reset_groups", "rg_set_schedule", "rg_drain_applied",
+    "rg_set_connected", "rg_set_side", "rg_crash", "rg_restart", "rg_kill", "rg_set_unreliable", "rg_set_unreliable_group", "rg_reset_groups", "rg_set_schedule", "rg_drain_applied",
     "rg_snapshot_export", "rg_snapshot_import", "rg_rpc_request_vote", "rg_rpc_append_entries",
     "rg_read_state", "rg_write_state", "rg_state_hash", "rg_counters", "rg_rpc_bytes", "rg_safety_check", "rg_safety_flags",
-    "rg_device_buffers",
+    "rg_device_buffers", "rg_safety_summary", "rg_comm_unique_id", "rg_comm_init", "rg_comm_destroy", "rg_allreduce_summary",
 ]
 
 _lib = None
@@ -163,6 +169,7 @@ def load_library(path=None):
         "rg_set_side": ([vp, i32, i32, i32], C.c_int),
         "rg_crash": ([vp, i32, i32], C.c_int),
         "rg_restart": ([vp, i32, i32], C.c_int),
+        "rg_kill": ([vp, i32, i32], C.c_int),
         "rg_set_unreliable": ([vp, i32, i32, i32], C.c_int),
         "rg_set_unreliable_group": ([vp, i32, i32, i32, i32], C.c_int),
         "rg_reset_groups": ([vp, P(i32), i64], C.c_int),
@@ -180,6 +187,11 @@ def load_library(path=None):
         "rg_safety_check": ([vp], C.c_int),
         "rg_safety_flags": ([vp, P(C.c_uint32)], C.c_int),
         "rg_device_buffers": ([vp, P(vp), P(vp)], C.c_int),
+        "rg_safety_summary": ([vp, P(C.c_uint64)], C.c_int),
+        "rg_comm_unique_id": ([vp], C.c_int),
+        "rg_comm_init": ([vp, i32, i32, vp], C.c_int),
+        "rg_comm_destroy": ([vp], C.c_int),
+        "rg_allreduce_summary": ([vp, vp, P(C.c_uint64), P(C.c_uint64)], C.c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)

@@ -99,6 +99,9 @@ struct rg_engine {
   bool specWanted;
   hipModule_t specMod; hipFunction_t specFn;
   bool specExt, specLean; DevCfg specFor;
+  // the cross-GPU exchange: counters + safety summary packed in one device buffer, reduced in place
+  u64 *redBuf;                    // device: [RG_N_COUNTERS + RG_N_SUMMARY]
+  void *comm;                     // ncclComm_t made by rg_comm_init, or null
 };
 
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { return RG_ERR_HIP; } } while (0)
@@ -225,6 +228,7 @@ static int init_state(rg_engine *e) {
   return RG_OK;
 }
 
+static void comm_release(void *comm);   // ncclCommDestroy, below with the rest of the RCCL plumbing
 static void free_engine(rg_engine *e) {
   for (auto &pr : e->pendingEv) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   for (void *p : e->allocs) hipFree(p);
@@ -232,6 +236,7 @@ static void free_engine(rg_engine *e) {
   if (e->hCmd) hipHostFree(e->hCmd);
   if (e->ownStream) hipStreamDestroy(e->ownStream);
   if (e->specMod) hipModuleUnload(e->specMod);
+  if (e->comm) comm_release(e->comm);
   delete e;
 }
 
@@ -294,6 +299,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (rc == RG_OK) rc = dalloc(e, &S.gflags, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.counters, (size_t)RG_CTR_SLOTS);
   if (rc == RG_OK) rc = dalloc(e, &S.flagSummary, (size_t)2);
+  if (rc == RG_OK) rc = dalloc(e, &e->redBuf, (size_t)(RG_N_COUNTERS + RG_N_SUMMARY));
   if (rc != RG_OK) { free_engine(e); return rc; }
   e->drained.assign((size_t)e->G * e->P, 0);
   e->applyCap = cfg->apply_ring_cap; e->applyRing = nullptr; e->applyHead = nullptr; e->netCfg = nullptr; e->sched = nullptr; e->schedN = 0; e->schedCap = 0;
@@ -771,6 +777,7 @@ extern "C" int rg_get_state(rg_engine *e, int32_t g, int32_t p, int32_t *term, i
 extern "C" int rg_set_connected(rg_engine *e, int32_t g, int32_t p, int32_t on) { LOCK(e); return run_one(e, on ? OP_CONNECT : OP_DISCONNECT, g, p, 0, nullptr); }
 extern "C" int rg_set_side(rg_engine *e, int32_t g, int32_t p, int32_t side) { LOCK(e); return run_one(e, (side & 1) ? OP_SIDE1 : OP_SIDE0, g, p, 0, nullptr); }
 extern "C" int rg_crash(rg_engine *e, int32_t g, int32_t p) { LOCK(e); return run_one(e, OP_CRASH, g, p, 0, nullptr); }
+extern "C" int rg_kill(rg_engine *e, int32_t g, int32_t p) { LOCK(e); return run_one(e, OP_KILL, g, p, 0, nullptr); }
 extern "C" int rg_restart(rg_engine *e, int32_t g, int32_t p) {
   LOCK(e);
   return run_one(e, OP_RESTART, g, p, 0, nullptr);   // the new instance replays from index 1 (raft.go:717) into the same apply ring
@@ -1166,6 +1173,11 @@ static int rw_state(rg_engine *e, int field, void *buf, int64_t bytes, bool wr) 
     for (int g = 0; g < G; g++) for (int p = 0; p < P; p++) {
       int &wv = tmp[(size_t)g * PP + p];
       int32_t &hv = b[(size_t)g * P + p];
+      if (field == RG_F_DEAD) {                      // 0 alive, 1 crashed, 2 killed: two bits of the flag word
+        if (!wr) hv = ((unsigned)wv & F_DEAD) ? (((unsigned)wv & F_ZOMBIE) ? 2 : 1) : 0;
+        else wv = (int)(((unsigned)wv & ~(F_DEAD | F_ZOMBIE)) | (hv ? F_DEAD : 0u) | (hv == 2 ? F_ZOMBIE : 0u));
+        continue;
+      }
       if (!wr) hv = isFlag ? (int)(((unsigned)wv >> shift) & mask) : wv;
       else if (isFlag) wv = (int)(((unsigned)wv & ~(mask << shift)) | (((unsigned)hv & mask) << shift));
       else wv = hv;
@@ -1307,6 +1319,116 @@ extern "C" int rg_safety_flags(rg_engine *e, uint32_t *out) {
   hipLaunchKernelGGL(k_flag_summary, dim3((e->G + 255) / 256), dim3(256), 0, e->stream, e->S, e->G);
   HIPCHK(hipGetLastError());
   return d2h(e, out, e->S.flagSummary, 8);
+}
+
+// Packs counters and safety summary of this engine's groups into redBuf (on the engine's stream).
+static int pack_summary(rg_engine *e) {
+  HIPCHK(hipMemsetAsync(e->redBuf, 0, (RG_N_COUNTERS + RG_N_SUMMARY) * sizeof(u64), e->stream));
+  hipLaunchKernelGGL(k_summary, dim3((e->G + 255) / 256), dim3(256), 0, e->stream, e->S, e->G, e->P, e->PP,
+                     (unsigned long long)e->G * (unsigned long long)e->now, (unsigned long long *)e->redBuf);
+  HIPCHK(hipGetLastError());
+  return RG_OK;
+}
+
+extern "C" int rg_safety_summary(rg_engine *e, uint64_t *out) {
+  LOCK(e);
+  if (!out) return RG_ERR_ARG;
+  int rc = pack_summary(e);
+  if (rc != RG_OK) return rc;
+  return d2h(e, out, e->redBuf + RG_N_COUNTERS, RG_N_SUMMARY * sizeof(u64));
+}
+
+// ---------------------------------------------------------------- RCCL, loaded when first needed
+// The declarations below restate the four entry points used, as rccl.h publishes them; nothing is linked.
+typedef struct { char internal[RG_COMM_ID_BYTES]; } rg_nccl_id;      // ncclUniqueId: 128 opaque bytes, passed by value
+struct Rccl {
+  void *lib = nullptr;
+  int (*getUniqueId)(rg_nccl_id *) = nullptr;
+  int (*commInitRank)(void **comm, int nranks, rg_nccl_id id, int rank) = nullptr;
+  int (*commDestroy)(void *comm) = nullptr;
+  int (*allReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t stream) = nullptr;
+  const char *(*errorString)(int) = nullptr;
+};
+enum { RG_NCCL_SUM = 0, RG_NCCL_UINT64 = 5 };                        // ncclSum, ncclUint64
+static const Rccl *rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+#define RCCL_SYM(field, sym) r.field = (decltype(r.field))dlsym(r.lib, #sym)
+    RCCL_SYM(getUniqueId, ncclGetUniqueId); RCCL_SYM(commInitRank, ncclCommInitRank); RCCL_SYM(commDestroy, ncclCommDestroy);
+    RCCL_SYM(allReduce, ncclAllReduce); RCCL_SYM(errorString, ncclGetErrorString);
+#undef RCCL_SYM
+    if (!(r.getUniqueId && r.commInitRank && r.commDestroy && r.allReduce)) r.lib = nullptr;
+  });
+  return r.lib ? &r : nullptr;
+}
+static int rccl_fail(const Rccl *r, const char *what, int st) {
+  fprintf(stderr, "raftgpu: %s: %s\n", what, r->errorString ? r->errorString(st) : "RCCL error");
+  return RG_ERR_HIP;
+}
+
+static void comm_release(void *comm) { const Rccl *r = rccl(); if (r) r->commDestroy(comm); }
+
+extern "C" int rg_comm_unique_id(void *id_out) {
+  if (!id_out) return RG_ERR_ARG;
+  const Rccl *r = rccl();
+  if (!r) return RG_ERR_STATE;
+  rg_nccl_id id;
+  const int st = r->getUniqueId(&id);
+  if (st != 0) return rccl_fail(r, "ncclGetUniqueId", st);
+  memcpy(id_out, &id, sizeof id);
+  return RG_OK;
+}
+
+extern "C" int rg_comm_init(rg_engine *e, int32_t rank, int32_t n_ranks, const void *idp) {
+  LOCK(e);
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !idp)) return RG_ERR_ARG;
+  if (e->comm) return RG_ERR_STATE;
+  const Rccl *r = rccl();
+  if (!r) return RG_ERR_STATE;
+  rg_nccl_id id;
+  if (idp) memcpy(&id, idp, sizeof id);
+  else { const int st = r->getUniqueId(&id); if (st != 0) return rccl_fail(r, "ncclGetUniqueId", st); }
+  void *comm = nullptr;
+  const int st = r->commInitRank(&comm, n_ranks, id, rank);
+  if (st != 0 || !comm) return rccl_fail(r, "ncclCommInitRank", st);
+  e->comm = comm;
+  return RG_OK;
+}
+
+extern "C" int rg_comm_destroy(rg_engine *e) {
+  LOCK(e);
+  if (!e->comm) return RG_OK;
+  const Rccl *r = rccl();
+  if (!r) return RG_ERR_STATE;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const int st = r->commDestroy(e->comm);
+  e->comm = nullptr;
+  return st == 0 ? RG_OK : rccl_fail(r, "ncclCommDestroy", st);
+}
+
+extern "C" int rg_allreduce_summary(rg_engine *e, void *nccl_comm, uint64_t *counters_out, uint64_t *summary_out) {
+  LOCK(e);
+  int rc = pack_summary(e);
+  if (rc != RG_OK) return rc;
+  void *comm = nccl_comm ? nccl_comm : e->comm;
+  if (comm) {
+    const Rccl *r = rccl();
+    if (!r) return RG_ERR_STATE;
+    const int st = r->allReduce(e->redBuf, e->redBuf, (size_t)(RG_N_COUNTERS + RG_N_SUMMARY), RG_NCCL_UINT64, RG_NCCL_SUM, comm, e->stream);
+    if (st != 0) return rccl_fail(r, "ncclAllReduce", st);
+  }
+  u64 host[RG_N_COUNTERS + RG_N_SUMMARY];
+  rc = d2h(e, host, e->redBuf, sizeof host);
+  if (rc != RG_OK) return rc;
+  if (counters_out) memcpy(counters_out, host, RG_N_COUNTERS * sizeof(u64));
+  if (summary_out) memcpy(summary_out, host + RG_N_COUNTERS, RG_N_SUMMARY * sizeof(u64));
+  return RG_OK;
 }
 
 extern "C" int rg_device_buffers(rg_engine *e, void **counters_dev, void **flag_summary_dev) {

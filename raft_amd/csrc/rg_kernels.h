@@ -5,7 +5,7 @@
 
 // ---------------------------------------------------------------- host-verb kernels
 // One thread per command; commands of one launch touch distinct groups.
-enum { OP_START = 0, OP_CONNECT, OP_DISCONNECT, OP_SIDE0, OP_SIDE1, OP_CRASH, OP_RESTART, OP_GETSTATE };
+enum { OP_START = 0, OP_CONNECT, OP_DISCONNECT, OP_SIDE0, OP_SIDE1, OP_CRASH, OP_RESTART, OP_GETSTATE, OP_KILL };
 struct HostCmd { int op, group, peer, pad; u64 arg; int r0, r1, r2, r3; };
 
 __global__ void k_host_cmds(DevPtrs S, DevCfg c, int PP, HostCmd *cmds, int n, int now) {
@@ -33,8 +33,9 @@ __global__ void k_host_cmds(DevPtrs S, DevCfg c, int PP, HostCmd *cmds, int n, i
     case OP_DISCONNECT: r.flags &= ~F_CONNECTED; break;
     case OP_SIDE0: r.flags &= ~F_SIDE; break;
     case OP_SIDE1: r.flags |= F_SIDE; break;
-    case OP_CRASH: r.flags &= ~F_CONNECTED; r.flags |= F_DEAD; break;
-    case OP_RESTART: r.flags &= ~F_CONNECTED; r.flags |= F_DEAD; make_peer(r, lg, sn, p, c.L, key, now, &sctr); break;
+    case OP_CRASH: r.crash(); break;
+    case OP_KILL: r.kill(); break;
+    case OP_RESTART: r.crash(); make_peer(r, lg, sn, p, c.L, key, now, &sctr); break;
     case OP_GETSTATE: cm.r1 = r.term; cm.r2 = r.isLeader() ? 1 : 0; break;
     }
     r.store(S, gl);
@@ -236,6 +237,32 @@ __global__ void k_flag_summary(DevPtrs S, int G) {
   if (f) { atomicOr(&S.flagSummary[0], f); atomicAdd(&S.flagSummary[1], 1u); }
 }
 
+// Counters and safety summary of the engine's groups, packed for one reduction: out[0 .. RG_N_COUNTERS) = the counter
+// block (group-ticks from the host's clock), out[RG_N_COUNTERS ..) = RG_S_* (zeroed by the caller).  One thread per group.
+__global__ void k_summary(DevPtrs S, int G, int P, int PP, unsigned long long groupTicks, unsigned long long *out) {
+  __shared__ unsigned long long acc[RG_N_SUMMARY];
+  if (threadIdx.x < RG_N_SUMMARY) acc[threadIdx.x] = 0;
+  __syncthreads();
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) {
+    const unsigned f = S.gflags[g];
+    unsigned long long rounds = 0;
+    for (int p = 0; p < P; p++) rounds += (unsigned)S.roundSeq[(size_t)g * PP + p];
+    const unsigned long long rec = (unsigned long long)S.recMax[g];
+    atomicAdd(&acc[RG_S_ROUNDS_ALL], rounds);
+    atomicAdd(&acc[RG_S_RECORDED_ALL], rec);
+    if (f) {
+      for (int b = 0; b < RG_N_FLAG_BITS; b++) if ((f >> b) & 1u) atomicAdd(&acc[RG_S_BIT_GROUPS + b], 1ull);
+      atomicAdd(&acc[RG_S_FLAGGED_GROUPS], 1ull);
+      atomicAdd(&acc[RG_S_ROUNDS_FLAGGED], rounds);
+      atomicAdd(&acc[RG_S_RECORDED_FLAGGED], rec);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < RG_N_SUMMARY && acc[threadIdx.x]) atomicAdd(&out[RG_N_COUNTERS + threadIdx.x], acc[threadIdx.x]);
+  if (blockIdx.x == 0 && threadIdx.x < RG_N_COUNTERS) out[threadIdx.x] = threadIdx.x == RG_C_GROUP_TICKS ? groupTicks : S.counters[threadIdx.x];
+}
+
 // state digest: order-free sum of per-word hashes, one lane per (group, peer)
 template <int PP>
 __global__ __launch_bounds__(256) void k_hash(DevPtrs S, DevCfg c, u64 *out) {
@@ -251,7 +278,7 @@ __global__ __launch_bounds__(256) void k_hash(DevPtrs S, DevCfg c, u64 *out) {
     v[RG_F_TERM] = S.term[gl]; v[RG_F_VOTE] = S.vote[gl]; v[RG_F_STATE] = (int)(f & F_STATE_MASK); v[RG_F_COMMIT] = S.commit[gl];
     v[RG_F_APPLIED] = S.applied[gl]; v[RG_F_LOGLEN] = S.logLen[gl]; v[RG_F_TIMER] = S.timer[gl]; v[RG_F_TIMEOUT] = S.timeout[gl];
     v[RG_F_HBTIMER] = S.hbTimer[gl]; v[RG_F_STOP] = (f & F_STOP) ? 1 : 0; v[RG_F_CNT] = (int)((f & F_CNT_MASK) >> F_CNT_SHIFT);
-    v[RG_F_DEAD] = (f & F_DEAD) ? 1 : 0; v[RG_F_RESTART] = (f & F_RESTART) ? 1 : 0; v[RG_F_FIRST] = (f & F_FIRST) ? 1 : 0;
+    v[RG_F_DEAD] = (f & F_DEAD) ? ((f & F_ZOMBIE) ? 2 : 1) : 0; v[RG_F_RESTART] = (f & F_RESTART) ? 1 : 0; v[RG_F_FIRST] = (f & F_FIRST) ? 1 : 0;
     v[RG_F_MONALIVE] = (f & F_MONALIVE) ? 1 : 0; v[RG_F_ELNEXT] = S.elNext[gl]; v[RG_F_MONNEXT] = S.monNext[gl];
     v[RG_F_RNGCTR] = S.rngCtr[gl]; v[RG_F_ROUNDSEQ] = S.roundSeq[gl]; v[RG_F_SNAPHAS] = (f & F_SNAPHAS) ? 1 : 0;
     v[RG_F_SNAPTERM] = S.snapTerm[gl]; v[RG_F_SNAPVOTE] = S.snapVote[gl]; v[RG_F_SNAPLEN] = S.snapLen[gl];

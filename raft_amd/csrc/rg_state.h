@@ -48,6 +48,7 @@ struct DevCfg {
 #define F_CNT_MASK  (7u << F_CNT_SHIFT)
 #define F_CDIRTY    (1u << 13)   // leader matrices changed since the commit rule last ran
 #define F_SNAPEXT   (1u << 14)   // the persisted log lives in the snapshot rows (imported blob), not in the log rows
+#define F_ZOMBIE    (1u << 15)   // with F_DEAD: killed by Kill() alone (raft.go:377-380), its server is still on the net
 
 #define STREAM_ELECTION 1ull
 #define STREAM_NET      2ull
@@ -135,6 +136,12 @@ struct LaneT {
   __device__ void setCnt(int c) { flags = (flags & ~F_CNT_MASK) | ((unsigned)c << F_CNT_SHIFT); }
   // GetState(), raft.go:90-100
   __device__ bool isLeader() const { return (flags & (F_DEAD | F_STOP | F_STATE_MASK)) == (unsigned)RG_LEADER; }
+  // can a Call reach this peer's handler: alive, or only Kill()ed (the handler then returns at once, raft.go:203,273)
+  __device__ bool served() const { return (flags & (F_DEAD | F_ZOMBIE)) != F_DEAD; }
+  // crash1, config.go:99-127: off the net, server deleted, dead
+  __device__ void crash() { flags = (flags & ~(F_CONNECTED | F_ZOMBIE)) | F_DEAD; }
+  // Kill(), raft.go:377-380: the dead flag alone
+  __device__ void kill() { if (!(flags & F_DEAD)) flags |= F_DEAD | F_ZOMBIE; }
 
   __device__ void load(const DevPtrs &S, long long gl) {
     term = S.term[gl]; vote = S.vote[gl]; flags = (unsigned)S.flags[gl]; commit = S.commit[gl]; cd(CD_APPLIED) = S.applied[gl];
@@ -212,7 +219,7 @@ __device__ static inline int next_random(LN &r, u64 key, int peer) {
 // back disconnected.
 template <class LN>
 __device__ static inline void make_peer(LN &r, const Rows &lg, const Rows &sn, int col, int L, u64 key, int now, WaveCtr *w) {
-  r.flags &= ~(F_DEAD | F_STATE_MASK | F_STOP | F_CNT_MASK | F_MONALIVE | F_FIRST | F_RESTART | F_CDIRTY);
+  r.flags &= ~(F_DEAD | F_ZOMBIE | F_STATE_MASK | F_STOP | F_CNT_MASK | F_MONALIVE | F_FIRST | F_RESTART | F_CDIRTY);
   r.term = 0; r.vote = -1;
   *lg.termp(0, col) = 0; *lg.cmdp(0, col) = 0;
   r.logLen = 1; r.commit = 0; r.cd(CD_APPLIED) = 0; r.timer = now; r.hbTimer = now;

@@ -108,10 +108,15 @@ struct NetRates { int reqDrop, replyDrop, replyDelay; };     // the net model's 
 __device__ static inline NetRates unpack_rates(unsigned w) { NetRates n; n.reqDrop = (int)(w & 1023u); n.replyDrop = (int)((w >> 10) & 1023u); n.replyDelay = (int)((w >> 20) & 1023u); return n; }
 __device__ static inline int net_outcome(const NetRates &c, u64 key, bool reachable, int s, int j, unsigned seq, int &cost) {
   cost = RG_RPC_WAIT_MS;
-  if (!reachable) return 0;
-  if ((c.reqDrop | c.replyDrop | c.replyDelay) == 0) { cost = 0; return 2 | NET_WIRE; }
+  const bool quiet = (c.reqDrop | c.replyDrop | c.replyDelay) == 0;
+  if (reachable && quiet) { cost = 0; return 2 | NET_WIRE; }
   const u64 h = stream_hash(key, STREAM_NET, ((unsigned)s << 8) | (unsigned)j, seq);
   const unsigned lo = (unsigned)h, hi = (unsigned)(h >> 32);
+  if (!reachable) {                               // labrpc.go:290-305: Call returns false after 0..6999 ms
+    const int ms = (int)(((u64)hi * 7000ull) >> 32);
+    cost = ms < RG_RPC_WAIT_MS ? ms : RG_RPC_WAIT_MS;
+    return 0;
+  }
   const int d = (int)((((hi >> 16) & 0xFFu) * (unsigned)RG_NET_DELAY_SPAN_MS) >> 8);          // labrpc.go:222, 0..26
   const int back = d < RG_RPC_WAIT_MS ? d : RG_RPC_WAIT_MS;
   if (permille_of(lo & 0xFFFFu) < c.reqDrop) { cost = back; return 0; }
@@ -533,11 +538,12 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
             const int up = __popc(G.ballot(valid && r.has(F_CONNECTED)));
             if (kind == RG_OP_CONNECT_IF_FEWER && me && up < op.b) r.flags |= F_CONNECTED;
           }
-          if (kind == RG_OP_CRASH && me) { r.flags &= ~F_CONNECTED; r.flags |= F_DEAD; }
+          if (kind == RG_OP_CRASH && me) r.crash();
+          if (kind == RG_OP_KILL && me) r.kill();
           const int alive = __popc(G.ballot(valid && !r.has(F_DEAD)));
           const bool again = kind == RG_OP_RESTART_IF_FEWER && me && r.has(F_DEAD) && alive < op.b;
           if ((kind == RG_OP_RESTART && me) || again) {                    // start1: crash1, then Make + readPersist
-            r.flags &= ~F_CONNECTED; r.flags |= F_DEAD;
+            r.crash();
             make_peer(r, lg, sn, peer, L, key, now, w);
             lVerified = 0;
 #pragma unroll
@@ -609,10 +615,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
         }
         r.flags |= F_CONNECTED;
       }
-      if ((int)((unsigned)(h3 & 0xFFFFF) % 1000u) < c.churnCrash && peer == (int)((h3 >> 32) % (u64)P) && !r.has(F_DEAD)) {
-        r.flags &= ~F_CONNECTED;
-        r.flags |= F_DEAD;
-      }
+      if ((int)((unsigned)(h3 & 0xFFFFF) % 1000u) < c.churnCrash && peer == (int)((h3 >> 32) % (u64)P) && !r.has(F_DEAD)) r.crash();
     }
     STAMP(10);
     client_starts(run, t);
@@ -706,12 +709,15 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           const unsigned fS = G.shflu(r.flags, sIdx);
           if (wantRV) r.cd(CD_ROUNDSEQ) = (int)(seq + 1u);
           const bool tgt = inR && valid && peer != s;
-          const bool reach = tgt && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
+          const bool reach = tgt && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && r.served();
           int cost = 0;
           const int outW = tgt ? net_outcome(net, key, reach, s, peer, seq, cost) : 0;
           const int out = outW & 3;
           VoteDecision d; d.rTerm = 0; d.touch = d.raise = d.grant = false;
-          if (out != 0) d = decide_vote(r, r.cd(CD_CTERM), T, s, lli, llt);
+          if (out != 0) {
+            if (r.has(F_DEAD)) d.rTerm = T;       // a Kill()ed peer: the shared reply stays as it is (raft.go:203, 585-588)
+            else d = decide_vote(r, r.cd(CD_CTERM), T, s, lli, llt);
+          }
           const unsigned sdm = G.ballot(out == 2 && d.rTerm > T);      // raft.go:622
           const int b = sdm ? (__ffs((int)sdm) - 1) : NONE;
           const bool called = tgt && peer <= b, ran = out != 0 && peer <= b, ok = out == 2 && peer <= b;
@@ -829,7 +835,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           const unsigned ovm = G.ballot(tgt && nx > lenS);           // raft.go:451-454 ends the round
           const int firstOv = ovm ? (__ffs((int)ovm) - 1) : NONE;
           const bool tgt2 = tgt && peer < firstOv;
-          const bool reach = tgt2 && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && !r.has(F_DEAD);
+          const bool reach = tgt2 && (fS & F_CONNECTED) && r.has(F_CONNECTED) && ((fS ^ r.flags) & F_SIDE) == 0 && r.served();
           int cost = 0;
           const int outW = tgt2 ? net_outcome(net, key, reach, s, peer, seq, cost) : 0;
           const int out = outW & 3;
@@ -857,7 +863,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
               WAIT_LOADS();
             }
           }
-          if (out != 0) d = decide_append<false>(r, lg, peer, T, prev, prevTerm, myPrevTerm);
+          // (a Kill()ed peer leaves the reply as the leader made it, raft.go:273, 456-461: {0, false, 0, 0})
+          if (out != 0 && !r.has(F_DEAD)) d = decide_append<false>(r, lg, peer, T, prev, prevTerm, myPrevTerm);
           {   // raft.go:308-313, the walk back to the first index of the conflicting term: by the wave, 64 entries a step
             u64 cm = __builtin_amdgcn_ballot_w64(out == 2 && d.ci == RG_CI_PENDING);   // only a reply that arrives carries it
             if (cm) {

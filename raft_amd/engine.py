@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _abi
 from ._abi import (AppendArgs, AppendReply, ApplyMsgC, Config, StartReq, VoteArgs, VoteReply, COUNTERS, FIELDS,
-                   N_COUNTERS)
+                   N_COUNTERS, N_SUMMARY, SUMMARY)
 
 
 class RaftGpuError(RuntimeError):
@@ -67,6 +67,13 @@ class EngineBase(object):
         self._check(self._fn("safety_flags")(self._h, buf), "safety_flags")
         return int(buf[0]), int(buf[1])
 
+    def safety_summary(self):
+        """Groups per safety-flag bit, flagged groups, and the share of the run's rounds and recorded entries that
+        fell in flagged groups (RG_S_*), as a dict."""
+        buf = (C.c_uint64 * N_SUMMARY)()
+        self._check(self._fn("safety_summary")(self._h, buf), "safety_summary")
+        return {n: int(buf[i]) for i, n in enumerate(SUMMARY)}
+
     def safety_check(self):
         self._check(self._fn("safety_check")(self._h), "safety_check")
         return self.safety_flags()
@@ -97,6 +104,10 @@ class EngineBase(object):
 
     def crash(self, g, p):
         self._check(self._fn("crash")(self._h, g, p), "crash")
+
+    def kill(self, g, p):
+        """rf.Kill() (src/raft/raft.go:377-380): the dead flag alone; the peer stays on the net."""
+        self._check(self._fn("kill")(self._h, g, p), "kill")
 
     def restart(self, g, p):
         self._check(self._fn("restart")(self._h, g, p), "restart")
@@ -246,6 +257,30 @@ class Engine(EngineBase):
         ta, ca = (C.c_int32 * max(1, ne))(*terms), (C.c_uint64 * max(1, ne))(*cmds)
         self._check(self._lib.rg_rpc_append_entries(self._h, n, ga, pa, aa, ta, ca, ne, ra), "rpc_append_entries")
         return [(r.term, bool(r.success), r.conflict_term, r.conflict_first_index) for r in ra]
+
+    # ---- the cross-GPU exchange (RCCL behind the C ABI) ----
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId through the library: 128 bytes for rank 0 to hand to the other ranks."""
+        lib = _abi.load_library()
+        buf = C.create_string_buffer(_abi.COMM_ID_BYTES)
+        st = lib.rg_comm_unique_id(buf)
+        if st != 0:
+            raise RaftGpuError(st, "rg_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank, n_ranks, unique_id=None):
+        buf = C.create_string_buffer(bytes(unique_id), _abi.COMM_ID_BYTES) if unique_id is not None else None
+        self._check(self._lib.rg_comm_init(self._h, int(rank), int(n_ranks), buf), "comm_init")
+
+    def comm_destroy(self):
+        self._check(self._lib.rg_comm_destroy(self._h), "comm_destroy")
+
+    def allreduce_summary(self, nccl_comm=None):
+        """(counters, summary) summed over every rank of the communicator: ONE ncclAllReduce on the engine's stream."""
+        c, s = (C.c_uint64 * N_COUNTERS)(), (C.c_uint64 * N_SUMMARY)()
+        self._check(self._lib.rg_allreduce_summary(self._h, C.c_void_p(nccl_comm), c, s), "allreduce_summary")
+        return ({n: int(c[i]) for i, n in enumerate(COUNTERS)}, {n: int(s[i]) for i, n in enumerate(SUMMARY)})
 
     def device_buffers(self):
         a, b = C.c_void_p(), C.c_void_p()

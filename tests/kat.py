@@ -475,10 +475,12 @@ def vote_test_reads_the_voters_own_entry(mk):
     assert e.request_vote(0, 2, 5, 1, 1, 1) == (5, False)     # LastLogIndex 1 < commitIndex 2 at equal terms
 
 
-def _net_call(seed, group, s, j, seq, req_drop, reply_drop, reply_delay):
+def _net_call(seed, group, s, j, seq, req_drop, reply_drop, reply_delay, reachable=True):
     """One Call on an unreliable net, restated from docs/LOCKSTEP.md "Network": (what happens, ms the sender waits)."""
     key = _sm64(_sm64(seed) ^ group)
     h = _sm64(key ^ (2 << 56) ^ (((s << 8) | j) << 32) ^ seq)
+    if not reachable:
+        return "unreachable", min(((h >> 32) * 7000) >> 32, 25)   # labrpc.go:290-305: Call returns false after 0..6999 ms
     d = (((h >> 48) & 0xFF) * 27) >> 8                       # labrpc.go:222: 0..26 ms
     permille = lambda x: (x * 1000) >> 16
     if permille(h & 0xFFFF) < req_drop:
@@ -661,6 +663,128 @@ def candidate_rounds_on_a_lossy_net(mk):
     return e
 
 
+def kill_leaves_the_peer_on_the_net(mk):
+    """rf.Kill() (raft.go:377-380) only sets the dead flag: the peer's handlers return at once (:203, :273) but labrpc
+    still delivers to its server, so Call returns true with the reply as the caller made it.  A leader therefore counts
+    a killed follower active (:476-477), reads {Term 0, Success false, ConflictTerm 0, ConflictFirstIndex 0} (:456-461)
+    and walks nextIndex down to 1 (:493-499: logs[0].Term == 0 == ConflictTerm); its silent-round counter never moves
+    (:514), unlike with a crashed follower (stop_rule).  A candidate counts killed peers active without their vote."""
+    e = mk(n_groups=1, n_peers=3, log_cap=16, seed=1)
+    e.step(30)
+    for cmd in (7, 8, 9):
+        assert e.start(0, 0, cmd)[2]
+        e.step(12)
+    assert e.read("nextindex")[0, 0].tolist()[1:] == [4, 4] and e.read("commit")[0].tolist() == [3, 3, 3]
+    e.kill(0, 2)
+    assert (e.read("dead")[0].tolist(), e.read("connected")[0].tolist()) == ([0, 0, 2], [1, 1, 1])
+    assert e.get_state(0, 2) == (1, False) and e.start(0, 2, 1) == (-1, 1, False)
+    before = e.counters()
+    timer2 = int(e.read("timer")[0, 2])
+    e.step(11)                                             # one heartbeat round (100 ms gate, raft.go:421)
+    c = e.counters()
+    assert c["ae_rounds"] - before["ae_rounds"] == 1
+    assert (c["rpc_sent"] - before["rpc_sent"], c["rpc_delivered"] - before["rpc_delivered"], c["rpc_replied"] - before["rpc_replied"]) == (2, 2, 2)
+    assert c["ae_conflicts"] == before["ae_conflicts"]     # the handler never reached :303
+    assert e.read("nextindex")[0, 0].tolist()[1:] == [4, 1]
+    assert e.read("matchindex")[0, 0, 2] == 3              # untouched
+    assert int(e.read("timer")[0, 2]) == timer2 and e.read("loglen")[0, 2] == 4
+    e.kill(0, 1)
+    e.step(100)                                            # ten more rounds that "reach" everybody: no stop (raft.go:514)
+    assert (e.read("cnt")[0, 0], e.read("stop")[0, 0]) == (0, 0) and e.get_state(0, 0) == (1, True)
+    assert e.read("nextindex")[0, 0].tolist()[1:] == [1, 1]
+    assert e.start(0, 0, 10) == (4, 1, True)
+    e.step(30)
+    assert e.read("commit")[0].tolist() == [3, 3, 3]       # nothing commits without a live majority
+    e.crash(0, 1)                                          # crash1 deletes the server (config.go:99-127): now unreachable
+    assert (e.read("dead")[0, 1], e.read("connected")[0, 1]) == (1, 0)
+    e.restart(0, 2)                                        # start1: a fresh peer from the Persister
+    assert (e.read("dead")[0, 2], e.read("connected")[0, 2], e.read("loglen")[0, 2]) == (0, 0, 4)
+    # a candidate among killed peers: both Calls come back true, neither carries a vote
+    e = mk(n_groups=1, n_peers=3, log_cap=16, seed=1)
+    e.kill(0, 1)
+    e.kill(0, 2)
+    _put(e, "state", 0, 0, 1)
+    e.step(1)
+    c = e.counters()
+    assert (c["rv_rounds"], c["rpc_sent"], c["rpc_delivered"], c["rpc_replied"], c["elections_won"]) == (1, 2, 2, 2, 0)
+    assert e.read("term")[0].tolist() == [1, 0, 0] and e.read("vote")[0].tolist() == [0, -1, -1]
+    assert (e.read("state")[0, 0], e.read("restart")[0, 0]) == (1, 1)
+    assert 50 <= e.read("elnext")[0, 0] <= 53              # no waits: both Calls returned at once on the reliable net
+
+
+def two_leaders_in_one_term(mk):
+    """The election loop's `restart` (raft.go:544) outlives a term change made by a handler: a candidate whose round
+    failed at term T sets restart (:660); a RequestVote of term T+1 then makes it a follower of T+1 and takes its vote
+    (:209-222); when it times out, its next round does NOT increment currentTerm (:569-573) but sets voteFor = me (:575):
+    a second vote in term T+1, and a second leader of T+1.  Five peers A..E = 0..4, partitions by side (both leaders
+    stay `connected`, which is what the tester's checkOneLeader looks at, config.go:307-320)."""
+    e = mk(n_groups=1, n_peers=5, log_cap=16, seed=1)
+    for p in range(5):
+        _put(e, "timer", 0, p, 1000000)                    # nobody times out unless told to
+    for p in (1, 2, 3, 4):
+        e.set_side(0, p, 1)                                # A alone
+    _put(e, "state", 0, 0, 1)
+    e.step(1)                                              # A's round at term 1 reaches nobody
+    assert (e.read("term")[0, 0], e.read("vote")[0, 0], e.read("restart")[0, 0], e.read("state")[0, 0]) == (1, 0, 1, 1)
+    assert e.read("elnext")[0, 0] >= 100                   # its retry lies beyond the next tick
+    for p, side in enumerate((0, 0, 0, 1, 1)):             # {A, B, C} | {D, E}
+        e.set_side(0, p, side)
+    _put(e, "term", 0, 1, 1)
+    _put(e, "state", 0, 1, 1)
+    _put(e, "elnext", 0, 1, 10)
+    e.step(1)                                              # B's round at term 2: A and C grant
+    assert e.get_state(0, 1) == (2, True)
+    assert e.read("term")[0].tolist() == [2, 2, 2, 0, 0] and e.read("vote")[0].tolist() == [1, 1, 1, -1, -1]
+    assert (e.read("state")[0, 0], e.read("restart")[0, 0]) == (0, 1)          # follower of term 2, restart still set
+    assert e.safety_flags() == (0, 0)
+    for p, side in enumerate((0, 1, 1, 0, 0)):             # {B, C} | {A, D, E}: B keeps a follower, so it never stops (:514)
+        e.set_side(0, p, side)
+    _put(e, "timer", 0, 0, -5000)                          # A times out at its next loop iteration
+    for _ in range(40):
+        e.step(1)
+        if e.get_state(0, 0)[1]:
+            break
+    assert e.get_state(0, 0) == (2, True) and e.get_state(0, 1) == (2, True)   # two leaders of term 2
+    assert e.read("vote")[0].tolist() == [0, 1, 1, 0, 0]                       # A voted for B and for itself in term 2
+    assert e.read("connected")[0].tolist() == [1] * 5
+    fl, n = e.safety_flags()
+    assert fl & _abi.FLAG_ELECTION_SAFETY and n == 1
+    return e
+
+
+def commit_index_past_a_truncated_log(mk):
+    """The vote test compares commitIndex and the term there (raft.go:218-219), so a candidate whose whole log is shorter
+    than a voter's commitIndex can win that vote with a newer term at its own commitIndex.  As leader it backs
+    nextIndex off (:493-505) until PrevLogIndex matches, and the voter's log becomes logs[0:Prev+1] ++ Entries whatever
+    its length was (:291-292); commitIndex is never lowered (:293-299), so commitIndex > len(logs)-1 and persist()
+    re-slices logs[0:commitIndex+1] past the end (:120: the stale entries of the backing array; apply() at :679 would
+    panic): RG_FLAG_REF_PANIC.  X = peer 1: log terms [0,3], commitIndex 1; Y = peer 2: [0,1,1,2,2], commitIndex 4."""
+    e = mk(n_groups=1, n_peers=3, log_cap=16, seed=1)
+    e.crash(0, 0)
+    _set_log(e, 0, 1, [0, 3], cmds=[0, 31], term=3, commit=1)
+    _set_log(e, 0, 2, [0, 1, 1, 2, 2], cmds=[0, 11, 12, 21, 22], term=3, commit=4)
+    _put(e, "applied", 0, 1, 1)
+    _put(e, "applied", 0, 2, 4)
+    _put(e, "state", 0, 1, 1)
+    e.step(1)                                              # X's round at term 4: {4, X, LastLogIndex 1, LastLogTerm 3} beats (4, term 2)
+    assert e.get_state(0, 1) == (4, True) and e.read("vote")[0, 2] == 1
+    assert e.read("nextindex")[0, 1, 2] == 2               # len(logs) of the new leader (:649-652)
+    seen_backoff = False
+    for _ in range(40):
+        e.step(1)
+        seen_backoff |= int(e.read("nextindex")[0, 1, 2]) == 1    # {ConflictTerm 1, first index 1}; the leader has no term-1 entry
+        if e.read("loglen")[0, 2] == 2:
+            break
+    assert seen_backoff
+    assert (e.read("loglen")[0, 2], e.read("commit")[0, 2]) == (2, 4)          # truncated below commitIndex
+    assert e.read("logterm")[0, 2, :2].tolist() == [0, 3] and e.read("logcmd")[0, 2, 1] == 31
+    assert e.read("snaplen")[0, 2] == 5                    # persist() at :300 took logs[0:5]
+    assert e.read("snaplogterm")[0, 2, :5].tolist() == [0, 3, 1, 2, 2]         # ... the new entry and the stale words behind it
+    fl, n = e.safety_flags()
+    assert fl & _abi.FLAG_REF_PANIC and n == 1
+    return e
+
+
 CASES = {f.__name__: f for f in (
     boot_and_three_starts, conflict_reply, append_truncates_unconditionally, leader_backoff, commit_rule,
     vote_compares_commit_index, restore_repersists_one_entry, start_on_isolated_leader, stop_rule,
@@ -669,4 +793,5 @@ CASES = {f.__name__: f for f in (
     failed_candidate_retries_same_term, rng_draw_points, apply_stream_keeps_what_was_applied,
     apply_ring_overrun_is_reported, vote_test_reads_the_voters_own_entry, a_failed_call_costs_its_short_delay,
     partitions_and_commands_follow_their_hashes, churn_follows_its_hashes,
-    election_loop_sleeps_with_its_slack, candidate_rounds_on_a_lossy_net)}
+    election_loop_sleeps_with_its_slack, candidate_rounds_on_a_lossy_net, kill_leaves_the_peer_on_the_net,
+    two_leaders_in_one_term, commit_index_past_a_truncated_log)}

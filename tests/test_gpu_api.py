@@ -34,7 +34,7 @@ def _seed_state(engines, rng, G, P, L):
     term = (terms[np.arange(G)[:, None], np.arange(P)[None, :], ln - 1] + rng.integers(0, 3, size=(G, P))).astype(np.int32)
     vote = rng.integers(-1, P, size=(G, P)).astype(np.int32)
     state = rng.integers(0, 3, size=(G, P)).astype(np.int32)
-    dead = (rng.random((G, P)) < 0.1).astype(np.int32)
+    dead = (rng.random((G, P)) < 0.1).astype(np.int32) * rng.integers(1, 3, size=(G, P)).astype(np.int32)   # crashed or killed
     for e in engines:
         e.write("logterm", terms)
         e.write("logcmd", cmds)
@@ -144,7 +144,9 @@ def test_read_write_roundtrip_every_field():
         cur = e.read(name)
         if name in ("state",):
             new = rng.integers(0, 3, size=cur.shape)
-        elif name in ("stop", "dead", "restart", "first", "monalive", "snaphas", "connected", "side"):
+        elif name == "dead":
+            new = rng.integers(0, 3, size=cur.shape)
+        elif name in ("stop", "restart", "first", "monalive", "snaphas", "connected", "side"):
             new = rng.integers(0, 2, size=cur.shape)
         elif name == "cnt":
             new = rng.integers(0, 5, size=cur.shape)
@@ -197,6 +199,37 @@ def test_state_digest_at_scale():
     commit = e.read("commit")
     assert (commit == 1000).all()
     assert (e.read("applyhash") == e.read("applyhash")[:, :1]).all()
+
+
+def test_summary_and_one_rank_allreduce():
+    """rg_safety_summary against the checker's, and rg_allreduce_summary through a one-rank RCCL communicator: the
+    reduction of one rank's words is those words (counters of rg_counters, summary of rg_safety_summary)."""
+    kw = dict(n_groups=700, n_peers=5, log_cap=128, seed=2, req_drop_permille=100, reply_drop_permille=100,
+              start_period=5, start_max=100, part_period=100, part_jitter=20)
+    o, e = _pair(**kw)
+    o.step_mt(3000, 8)
+    e.step(3000)
+    assert o.safety_check() == e.safety_check()
+    so, se = o.safety_summary(), e.safety_summary()
+    assert so == se
+    assert se["flagged_groups"] == e.safety_flags()[1] > 0
+    bits = sum(1 << i for i, n in enumerate(_abi.FLAG_NAMES) if se["groups_" + n])
+    assert bits == e.safety_flags()[0]
+    assert 0 < se["rounds_flagged"] < se["rounds_all"] == int(e.read("roundseq").sum())
+    assert se["recorded_all"] == int(e.read("recmax").sum())
+    # no communicator: the engine's own words
+    c0, s0 = e.allreduce_summary()
+    assert c0 == e.counters() and s0 == se
+    # a one-rank communicator made through the library (ncclCommInitRank, ncclAllReduce on the engine's stream)
+    e.comm_init(0, 1)
+    c1, s1 = e.allreduce_summary()
+    assert c1 == e.counters() and s1 == se
+    e.step(100)
+    c2, s2 = e.allreduce_summary()
+    assert c2 == e.counters() and c2["group_ticks"] == 700 * 3100 and s2 == e.safety_summary()
+    e.comm_destroy()
+    e.comm_destroy()                                  # idempotent
+    assert len(type(e).comm_unique_id()) == _abi.COMM_ID_BYTES
 
 
 def test_abi_from_plain_c():

@@ -35,8 +35,9 @@ def _random_config(rng):
     return kw
 
 
-def _random_ops(rng, peers, until):
-    """A scenario schedule: random verbs at random ticks, for every group alike."""
+def _random_ops(rng, peers, until, rk):
+    """A scenario schedule: random verbs at random ticks, for every group alike.  (rk: a stream of its own for verbs
+    added later, so that the cases of earlier seeds stay what they were.)"""
     ops, t = [], rng.randrange(5, 60)
     regs_set = set()
     while t < until:
@@ -62,6 +63,8 @@ def _random_ops(rng, peers, until):
             ops.append((t, _abi.OP_CONNECT_IF_FEWER, sel, rng.randrange(1, peers + 2)))
         else:
             ops.append((t, {"connect": _abi.OP_CONNECT, "disconnect": _abi.OP_DISCONNECT, "crash": _abi.OP_CRASH, "restart": _abi.OP_RESTART}[kind], sel, 0))
+        if rk.random() < 0.08:                        # rf.Kill(): dead, but still on the net (raft.go:377-380)
+            ops.append((t, _abi.OP_KILL, rk.choice([rk.randrange(peers), _abi.SEL_ALL] + [_abi.SEL_REG(r, rk.randrange(peers)) for r in sorted(regs_set)]), 0))
         t += rng.choice([0, 0, 1, 3, 10, 40, 120])
     return ops
 
@@ -118,10 +121,11 @@ def _run(seed, tweak=None, until=1500):
     if random.Random(77 + seed).random() < float(_ENV.get("RAFT_FUZZ_SPECIALIZE", "0.06")):   # (its own stream: the case stays the same)
         e.specialize()                                  # some cases run on a kernel compiled for their configuration
     if rng.random() < p_sched:
-        ops = _random_ops(rng, kw["n_peers"], until)
+        ops = _random_ops(rng, kw["n_peers"], until, random.Random(4242 + seed))
         o.set_schedule(ops)
         e.set_schedule(ops)
     t = 0
+    rk = random.Random(777 + seed)
     step = e.step_noalloc if random.Random(99 + seed).random() < 0.15 else e.step   # (its own stream) some cases through the entry point that allocates nothing
     while t < until:
         n = rng.choice([1, 1, 2, 3, 5, 8, 13, 50, 200, 600])
@@ -130,6 +134,10 @@ def _run(seed, tweak=None, until=1500):
         t += n
         d = diff_states(o, e)
         assert not d, "config %r after tick %d: %s" % (kw, t, "; ".join(d[:5]))
+        if rk.random() < 0.04:                      # rf.Kill() from the host
+            g, p = rk.randrange(kw["n_groups"]), rk.randrange(kw["n_peers"])
+            o.kill(g, p)
+            e.kill(g, p)
         if rng.random() < 0.2:                      # host verbs between launches
             g, p = rng.randrange(kw["n_groups"]), rng.randrange(kw["n_peers"])
             verb = rng.choice(["start", "disconnect", "connect", "crash", "restart", "move_blob", "vote", "append", "reset_group", "group_rates", "drain"])
@@ -190,3 +198,4 @@ def _run(seed, tweak=None, until=1500):
                     x.restart(g, p)
     assert np.array_equal(o.state_hash(), e.state_hash())
     assert o.safety_check() == e.safety_check()
+    assert o.safety_summary() == e.safety_summary()

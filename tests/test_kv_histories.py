@@ -14,7 +14,7 @@ NETS = {
 }
 
 
-SEEDS = {"partitions": 10}    # a seed under which one of the 8 groups loses a committed entry within 1500 ticks
+SEEDS = {"partitions": 5}    # a seed under which one of the 8 groups loses a committed entry within 1500 ticks
 
 
 def _histories(make_engine, net, groups=8, ticks=1500):
