@@ -4,6 +4,11 @@ package raft
 // is not copied here; a maintainer adds ONE line at each place named below, nothing else changes, and
 // test_test.go runs unmodified.
 
+/*
+#include "raftgpu.h"
+*/
+import "C"
+
 import "sync"
 
 var (
@@ -28,10 +33,13 @@ func hookMakeConfig(cfg *config, n int, unreliable bool) {
 
 // crash1, first line (config.go:100):  hookCrash(cfg, i)
 // persist() runs inside the engine; the Persister the harness is about to copy (config.go:110-126) gets the
-// peer's current blob first.
+// peer's current blob first.  Then the engine's crash1: off the net with its server deleted (what
+// cfg.net.DeleteServer(i), config.go:104, does to the labrpc network); rf.Kill() at config.go:117 finds it dead.
 func hookCrash(cfg *config, i int) {
-	if rf := cfg.rafts[i]; rf != nil {
+	if rf := cfg.rafts[i]; rf != nil { // (start1 of a server that never ran calls crash1 too: nothing to take down)
 		rf.SyncPersister()
+		grp := grpOf(cfg)
+		status(C.rg_crash(grp.en.e, grp.g, C.int32_t(i)), "rg_crash")
 	}
 }
 

@@ -101,6 +101,15 @@ func engineFor(n int) *engine {
 	c.seed = C.uint64_t(time.Now().UnixNano()) // config.go:30-35 seeds from crypto/rand
 	en := &engine{peers: n, groups: map[C.int32_t]*Group{}}
 	status(C.rg_create(&c, &en.e), "rg_create")
+	// rg_create boots every group; a slot nobody has taken must not elect, heartbeat or count RPCs (RPCTotal and
+	// BytesTotal read engine-wide counters): all peers crashed and off the net until BeginConfig's rg_reset_groups
+	// makes a slot's peers afresh.
+	parked := make([]C.int32_t, engineGroups*n)
+	status(C.rg_write_state(en.e, C.RG_F_CONNECTED, unsafe.Pointer(&parked[0]), C.int64_t(4*len(parked))), "rg_write_state(connected)")
+	for i := range parked {
+		parked[i] = 1
+	}
+	status(C.rg_write_state(en.e, C.RG_F_DEAD, unsafe.Pointer(&parked[0]), C.int64_t(4*len(parked))), "rg_write_state(dead)")
 	for g := engineGroups - 1; g >= 0; g-- {
 		en.free = append(en.free, C.int32_t(g))
 	}
@@ -233,11 +242,39 @@ func (rf *Raft) Start(command interface{}) (int, int, bool) {
 	return int(idx), int(term), lead != 0
 }
 
-// Kill, raft.go:377-385.
+// Kill, raft.go:377-385: the dead flag and nothing else -- the peer stays on the net (a Call to it still
+// returns true, with the reply untouched).  The tester's crash1 takes it off the net first (hookCrash).
 func (rf *Raft) Kill() {
 	if atomic.CompareAndSwapInt32(&rf.dead, 0, 1) {
-		status(C.rg_crash(rf.grp.en.e, rf.grp.g, C.int32_t(rf.me)), "rg_crash")
+		status(C.rg_kill(rf.grp.en.e, rf.grp.g, C.int32_t(rf.me)), "rg_kill")
 	}
+}
+
+// AllReduceSummary is the job's one cross-GPU exchange: this engine's counters (RG_C_*) and safety summary (RG_S_*),
+// summed over every rank of the communicator made with CommInit -- one ncclAllReduce over xGMI inside the library.
+// Every rank calls it at the same reporting boundaries.
+func AllReduceSummary(n int) (counters [C.RG_N_COUNTERS]uint64, summary [C.RG_N_SUMMARY]uint64) {
+	en := engineFor(n)
+	var c [C.RG_N_COUNTERS]C.uint64_t
+	var s [C.RG_N_SUMMARY]C.uint64_t
+	status(C.rg_allreduce_summary(en.e, nil, &c[0], &s[0]), "rg_allreduce_summary")
+	for i := range c {
+		counters[i] = uint64(c[i])
+	}
+	for i := range s {
+		summary[i] = uint64(s[i])
+	}
+	return
+}
+
+// CommUniqueId / CommInit: rank 0 makes the id, the host program carries its RG_COMM_ID_BYTES to the other ranks
+// (one process per GPU), every rank then joins.
+func CommUniqueId() (id [C.RG_COMM_ID_BYTES]byte) {
+	status(C.rg_comm_unique_id(unsafe.Pointer(&id[0])), "rg_comm_unique_id")
+	return
+}
+func CommInit(n, rank, nRanks int, id [C.RG_COMM_ID_BYTES]byte) {
+	status(C.rg_comm_init(engineFor(n).e, C.int32_t(rank), C.int32_t(nRanks), unsafe.Pointer(&id[0])), "rg_comm_init")
 }
 
 func (rf *Raft) killed() bool { return atomic.LoadInt32(&rf.dead) == 1 }

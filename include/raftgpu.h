@@ -216,8 +216,10 @@ int rg_step(rg_engine *e, int32_t n_ticks);
  * one copy per GPU, held until the process ends) instead of the buffers rg_create allocated; the launch is not
  * timed (rg_step_time_ms does not see it).  Engines too large for the array (more than about 4,600 sets of
  * 4 wavefronts' groups, e.g. 220,000 five-peer groups) get RG_ERR_SCRATCH and nothing is launched; engines that
- * fit the chip at once use no scratch and are never refused.  All engines on one GPU share the array: calls
- * that overlap in time on one GPU (different engines on different streams) race; serialise them. */
+ * fit the chip at once, and calls short enough for a plain launch (fewer than 2,000 ticks), use no scratch and are
+ * never refused.  All engines on one GPU share the array: a launch that uses it waits on the GPU (a stream wait on
+ * a per-device event, no allocation) until the previous launch that used it -- of any engine, on any stream -- has
+ * ended, so overlapping calls are serialised, not raced. */
 #define RG_NOALLOC_SCRATCH_BYTES (8u << 20)
 int rg_step_noalloc(rg_engine *e, int32_t n_ticks);
 /* Compiles the tick kernel for THIS engine's configuration.  No counterpart in the reference: Go compiles
@@ -228,8 +230,9 @@ int rg_step_noalloc(rg_engine *e, int32_t n_ticks);
  * time on large engines (fewer scalar registers, folded arithmetic).  A later change of what was compiled in
  * (rg_set_unreliable, an apply ring, a schedule or per-group rates appearing) rebuilds the kernel at the next
  * rg_step; rg_step_noalloc only uses a kernel that is already built and fits.  RG_ERR_STATE: hiprtc could not be
- * loaded; RG_ERR_HIP: the compile or the module load failed (the compiler's log goes to stderr); in both cases
- * the engine keeps running on the generic kernel.  Setting RAFTGPU_SPECIALIZE=1 in the environment does the same
+ * loaded; RG_ERR_HIP: the compile or the module load failed (the compiler's log goes to stderr); RG_ERR_ARG: the
+ * environment's RAFTGPU_SPEC_DEFS (extra compiler options, a tuning aid) holds an option that is not on the list
+ * of options the library passes on; in all cases the engine keeps running on the generic kernel.  Setting RAFTGPU_SPECIALIZE=1 in the environment does the same
  * for every engine at its first launch. */
 int rg_specialize(rg_engine *e);
 int rg_sync(rg_engine *e);
@@ -379,6 +382,13 @@ int rg_comm_init(rg_engine *e, int32_t rank, int32_t n_ranks, const void *id);
 int rg_comm_destroy(rg_engine *e);
 int rg_allreduce_summary(rg_engine *e, void *nccl_comm, uint64_t *counters_out /* RG_N_COUNTERS */,
                          uint64_t *summary_out /* RG_N_SUMMARY */);
+
+#if defined(RG_SECTION_COUNTS) || defined(RG_STAMPS)
+/* Diagnostic builds of the library only (compiled with -DRG_SECTION_COUNTS or -DRG_STAMPS for the scripts under profiles/; the
+ * shipped library does not export it): how often each section of the tick kernel ran and the shader cycles spent
+ * there, 56 words.  No counterpart in the reference. */
+int rg_debug_section_counts(rg_engine *e, uint64_t *out);
+#endif
 
 #ifdef __cplusplus
 }

@@ -49,7 +49,11 @@ typedef unsigned long long u64;
 static __device__ __align__(256) int scratch[RG_SCRATCH_INTS];
 #define RG_MAX_DEVICES 64
 static int *g_scratchPtr[RG_MAX_DEVICES];               // per device: address of that device's copy of scratch
-static std::mutex g_scratchMu;
+// Per device: recorded after every launch that uses the array; the next such launch, of whichever engine and on
+// whichever stream, waits for it first, so launches that share the array never overlap on the GPU.  Created once per
+// device (rg_create); waiting for and recording an event allocates nothing.
+static hipEvent_t g_scratchDone[RG_MAX_DEVICES];
+static std::mutex g_scratchMu;                          // also makes wait + launch + record one step per device
 // Address of the current device's copy; looked up once per device, with that device current.
 static int scratch_of(int device, int **out) {
   if (device < 0 || device >= RG_MAX_DEVICES) return RG_ERR_ARG;
@@ -57,6 +61,9 @@ static int scratch_of(int device, int **out) {
   if (!g_scratchPtr[device]) {
     void *p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return RG_ERR_HIP;
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return RG_ERR_HIP;
+    g_scratchDone[device] = ev;
     g_scratchPtr[device] = (int *)p;
   }
   *out = g_scratchPtr[device];
@@ -484,6 +491,52 @@ static int compile_spec(const Rtc *r, const std::vector<std::string> &opts, std:
   return RG_OK;
 }
 
+// RAFTGPU_SPEC_DEFS reaches a compiler whose option parser ends the PROCESS on an option it does not know, and this
+// library never aborts: only the options the tuning sweeps use get through.  -DRG_<NAME>[=<integer>], -O0..-O3 / -Os,
+// -f[no-]unroll-loops, and `-mllvm <opt>` for the back-end switches listed here with the values listed here.
+static bool spec_value_in(const std::string &v, std::initializer_list<const char *> ok) {
+  for (const char *o : ok) if (v == o) return true;
+  return false;
+}
+static bool spec_all_digits(const std::string &v) {
+  if (v.empty() || v.size() > 9) return false;
+  for (char ch : v) if (ch < '0' || ch > '9') return false;
+  return true;
+}
+static bool spec_mllvm_ok(const std::string &t) {
+  if (t.empty() || t[0] != '-') return false;
+  const size_t eq = t.find('=');
+  const std::string name = t.substr(1, eq == std::string::npos ? std::string::npos : eq - 1);
+  const std::string val = eq == std::string::npos ? "" : t.substr(eq + 1);
+  if (name == "amdgpu-sched-strategy") return spec_value_in(val, {"max-ilp", "max-memory-clause"});
+  if (name == "amdgpu-schedule-relaxed-occupancy" || name == "amdgpu-early-inline-all") return spec_value_in(val, {"true", "false"});
+  if (name == "amdgpu-sdwa-peephole" || name == "amdgpu-spill-sgpr-to-vgpr") return spec_value_in(val, {"0", "1"});
+  if (name == "tail-dup-size") return spec_all_digits(val);
+  if (name == "split-spill-mode") return spec_value_in(val, {"default", "size", "speed"});
+  if (name == "disable-phi-elim-edge-splitting") return eq == std::string::npos;
+  return false;
+}
+static bool spec_defs_ok(const std::vector<std::string> &toks) {
+  for (size_t i = 0; i < toks.size(); i++) {
+    const std::string &t = toks[i];
+    if (t == "-mllvm") { if (i + 1 >= toks.size() || !spec_mllvm_ok(toks[i + 1])) return false; i++; continue; }
+    if (spec_value_in(t, {"-O0", "-O1", "-O2", "-O3", "-Os", "-fno-unroll-loops", "-funroll-loops"})) continue;
+    if (t.compare(0, 5, "-DRG_") == 0) {
+      size_t j = 5;
+      while (j < t.size() && ((t[j] >= 'A' && t[j] <= 'Z') || (t[j] >= '0' && t[j] <= '9') || t[j] == '_')) j++;
+      if (j == 5) return false;
+      if (j == t.size()) continue;
+      if (t[j] != '=') return false;
+      std::string v = t.substr(j + 1);
+      if (!v.empty() && v[0] == '-') v = v.substr(1);
+      if (!spec_all_digits(v)) return false;
+      continue;
+    }
+    return false;
+  }
+  return true;
+}
+
 // Compiles and loads k_tick_spec for configuration c of the engine (device of the engine current).
 static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
   const Rtc *r = rtc();
@@ -507,12 +560,18 @@ static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
   def("ACCTBYTES", c.acctBytes);
   if (const char *x = getenv("RAFTGPU_SPEC_DEFS")) {          // tuning aid: extra compiler options, blank-separated
     const std::string t = x;
+    std::vector<std::string> extra;
     for (size_t i = 0; i < t.size();) {
       size_t j = t.find(' ', i);
       if (j == std::string::npos) j = t.size();
-      if (j > i) opts.push_back(t.substr(i, j - i));
+      if (j > i) extra.push_back(t.substr(i, j - i));
       i = j + 1;
     }
+    if (!spec_defs_ok(extra)) {
+      fprintf(stderr, "raftgpu: rg_specialize: RAFTGPU_SPEC_DEFS=\"%s\" holds an option that is not on the list of tuning options; nothing was compiled\n", x);
+      return RG_ERR_ARG;
+    }
+    opts.insert(opts.end(), extra.begin(), extra.end());
   }
   std::vector<char> code;
   int rc = compile_spec(r, opts, code);
@@ -624,14 +683,28 @@ extern "C" int rg_step_noalloc(rg_engine *e, int32_t n_ticks) {
   if (n_ticks < 0) return RG_ERR_ARG;
   if (n_ticks == 0) return RG_OK;
   if (e->now + n_ticks > RG_MAX_NOW_TICKS) return RG_ERR_RANGE;
-  if (e->relaySets > 0 && relay_queue_ints(e) + relay_stage_ints(e) > (size_t)RG_SCRATCH_INTS) return RG_ERR_SCRATCH;
+  bool relays = false;                                   // does any launch of this call go through the relay queue?
+  for (int rem = n_ticks; rem > 0; rem -= RG_MAX_LAUNCH_TICKS)
+    if (relay_chunk_ticks(e, rem < RG_MAX_LAUNCH_TICKS ? rem : RG_MAX_LAUNCH_TICKS) > 0) relays = true;
+  if (relays && relay_queue_ints(e) + relay_stage_ints(e) > (size_t)RG_SCRATCH_INTS) return RG_ERR_SCRATCH;
   int rc = run_derive(e);
   if (rc != RG_OK) return rc;
   int *const queue = e->scratchDev, *const stage = e->scratchDev + relay_queue_ints(e);
   while (n_ticks > 0) {
     const int n = n_ticks < RG_MAX_LAUNCH_TICKS ? n_ticks : RG_MAX_LAUNCH_TICKS;
-    rc = launch_kernel(e, n, queue, stage, false);      // clears the queue words it uses; the staging area is written before it is read
-    if (rc != RG_OK) return rc;
+    if (relay_chunk_ticks(e, n) > 0) {
+      // The array is the GPU's, not the engine's: this launch starts after the last one that used it has ended,
+      // whichever engine and stream that was.
+      std::lock_guard<std::mutex> lk(g_scratchMu);
+      hipEvent_t done = g_scratchDone[e->cfg.device];
+      HIPCHK(hipStreamWaitEvent(e->stream, done, 0));
+      rc = launch_kernel(e, n, queue, stage, false);    // clears the queue words it uses; the staging area is written before it is read
+      if (rc != RG_OK) return rc;
+      HIPCHK(hipEventRecord(done, e->stream));
+    } else {
+      rc = launch_kernel(e, n, queue, stage, false);    // a plain launch: no scratch
+      if (rc != RG_OK) return rc;
+    }
     e->now += n;
     n_ticks -= n;
   }

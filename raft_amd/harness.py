@@ -18,13 +18,25 @@ class TestFailure(AssertionError):
     __test__ = False     # not a pytest class
 
 
+def park_all(engine):
+    """An engine that serves one tester config per group (the Go binding's engineFor): rg_create boots every group,
+    and a group no config has taken must not elect, heartbeat or count RPCs -- the configs read engine-wide counters
+    (config.go:284-294).  Every peer crashed and off the net, until a Config's rg_reset_groups makes its group's
+    peers afresh."""
+    import numpy as np
+    engine.write("connected", np.zeros((engine.G, engine.P), dtype=np.int32))
+    engine.write("dead", np.ones((engine.G, engine.P), dtype=np.int32))
+
+
 class Config(object):
     """make_config (config.go:60-96) for group `group` of `engine`."""
 
-    def __init__(self, engine, group=0, unreliable=False):
+    def __init__(self, engine, group=0, unreliable=False, reset=None):
         self.engine, self.group = engine, group
         self.n = engine.P
-        self.net = Network(engine, group)
+        self.net = Network(engine, group, reset)
+        self.rpcs0 = engine.counters()["rpc_sent"]     # the counters are the engine's: a config reads what was added since it began
+        self.bytes0 = {}
         self.applyErr = [""] * self.n
         self.rafts = [None] * self.n
         self.connected = [False] * self.n
@@ -67,6 +79,8 @@ class Config(object):
     # ---- crash / restart (config.go:99-215) --------------------------------
     def crash1(self, i):
         self.disconnect(i)
+        if self.rafts[i] is not None:
+            self.engine.crash(self.group, i)      # cfg.net.DeleteServer(i), config.go:104: Calls no longer reach it
         if self.saved[i] is not None:
             self.saved[i] = self.saved[i].Copy()
         rf = self.rafts[i]
@@ -112,11 +126,11 @@ class Config(object):
         self.engine.set_unreliable_group(self.group, drop, drop, 667 if self.longreordering else 0)
 
     def rpcTotal(self):
-        return self.engine.counters()["rpc_sent"]
+        return self.engine.counters()["rpc_sent"] - self.rpcs0
 
     def bytesTotal(self, command_bytes=8):
         """config.go:292-294; command_bytes = size of the commands the caller's handles stand for."""
-        return self.engine.rpc_bytes(command_bytes)
+        return self.engine.rpc_bytes(command_bytes) - self.bytes0.get(command_bytes, 0)
 
     def rpcCount(self):
         """Sum over servers of delivered requests (labrpc.go:406)."""

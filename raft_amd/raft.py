@@ -228,10 +228,11 @@ class Raft(object):
         return t, (l and not self._dead)
 
     def Kill(self):
-        """reference: src/raft/raft.go:377-380"""
+        """reference: src/raft/raft.go:377-380: the dead flag alone (rg_kill).  The peer stays on the net; taking it
+        off is the tester's crash1 (Config.crash1 -> rg_crash)."""
         if not self._dead:
             self._dead = True
-            self._net.engine.crash(self._net.group, self.me)
+            self._net.engine.kill(self._net.group, self.me)
 
     def killed(self):
         return self._dead

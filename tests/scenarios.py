@@ -535,4 +535,35 @@ def labrpc_ends_reach_the_handlers(make_engine):
     return eng
 
 
-EXTRA = {"TwoConfigsOneEngine": two_configs_on_one_engine, "LabrpcEnds": labrpc_ends_reach_the_handlers}
+def parked_slots_stay_silent(make_engine):
+    """The Go binding keeps one 4,096-group engine per peer count and gives every tester config a group of it; its
+    rpcTotal / bytesTotal are deltas of the ENGINE's counters (config.go:284-294).  Groups no config has taken are
+    parked (every peer crashed and off the net), so the counts a config reads are its own: TestCount2B's ceilings
+    (test_test.go:461, 527, 546) hold on a 4,096-group engine as they do on a one-group engine."""
+    from raft_amd.harness import park_all
+    G = 4096
+    eng = make_engine(n_groups=G, n_peers=3, log_cap=64, seed=7, account_bytes=1, apply_ring_cap=64)
+    park_all(eng)
+    eng.step(150)
+    c = eng.counters()
+    assert (c["rpc_sent"], c["rv_rounds"], c["timeouts"], c["elections_won"]) == (0, 0, 0, 0)
+    cfg = Config(eng, 77, False, reset=True)
+    cfg.checkOneLeader()
+    total1 = cfg.rpcTotal()
+    assert 1 <= total1 <= 30, "too many or few RPCs (%d) to elect initial leader" % total1        # test_test.go:461
+    for i in range(10):
+        assert cfg.one(500 + i, 3, False) == i + 1
+    total2 = cfg.rpcTotal()
+    assert total2 - total1 <= (10 + 1 + 3) * 3, "too many RPCs (%d) for 10 entries" % (total2 - total1)   # test_test.go:527
+    cfg.advance(ET)
+    total3 = cfg.rpcTotal()
+    assert total3 - total2 <= 3 * 20, "too many RPCs (%d) for 1 second of idleness" % (total3 - total2)   # test_test.go:546
+    assert 0 < cfg.bytesTotal(8) < 4000
+    rounds = eng.read("roundseq").sum(axis=1)
+    assert rounds[77] > 0 and rounds.sum() == rounds[77]      # nobody else sent anything
+    assert eng.read("term")[:77].max() == 0 and eng.read("term")[78:].max() == 0
+    return eng
+
+
+EXTRA = {"TwoConfigsOneEngine": two_configs_on_one_engine, "LabrpcEnds": labrpc_ends_reach_the_handlers,
+         "ParkedSlots": parked_slots_stay_silent}

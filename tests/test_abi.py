@@ -12,12 +12,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
+    """What the header declares for the shipped library (the block for diagnostic builds left out)."""
     text = open(os.path.join(ROOT, "include", "raftgpu.h")).read()
+    text = re.sub(r"#if defined\(RG_SECTION_COUNTS\).*?#endif", "", text, flags=re.S)
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rg_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_header_and_loader_agree():
     assert _declared() == sorted(_abi.EXPORTS)
+
+
+def test_library_exports_exactly_what_the_header_declares():
+    """Both ways, from the library's own dynamic symbol table: nothing declared is missing, nothing exported is
+    undeclared."""
+    import subprocess
+    if not os.path.exists(_abi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", _abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TW" and ln.split()[-1].startswith("rg_"))
+    assert exported == _declared()
 
 
 def test_library_exports_every_declared_symbol():

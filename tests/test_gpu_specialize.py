@@ -56,6 +56,39 @@ def test_rebuilt_when_the_configuration_changes():
     assert o.counters() == e.counters()
 
 
+def test_unknown_compiler_options_are_refused_not_fatal(monkeypatch):
+    """RAFTGPU_SPEC_DEFS is a tuning aid that reaches a compiler whose option parser ends the process on an option it
+    does not know.  The library passes on only the options it lists: anything else is RG_ERR_ARG, the process lives
+    and the engine keeps running on the generic kernel."""
+    from oracle.binding import OracleEngine
+    from raft_amd import Engine, RaftGpuError
+    kw = CASES["lean_5"]
+    for bad in ("-mllvm -no-such-backend-switch=1", "-mllvm", "--version", "-DFOO=1", "-DRG_RING=4;x", "-mllvm -amdgpu-sched-strategy=bogus",
+                "-O3 -include /etc/passwd"):
+        monkeypatch.setenv("RAFTGPU_SPEC_DEFS", bad)
+        e = Engine(_abi.make_config(**kw))
+        with pytest.raises(RaftGpuError) as ei:
+            e.specialize()
+        assert ei.value.status == _abi.ERR_ARG, bad
+        e.step(50)                               # the generic kernel serves
+        assert e.now() == 50
+        e.close()
+    # options on the list go through, and the kernel they build is still the same function of the state
+    monkeypatch.setenv("RAFTGPU_SPEC_DEFS", "-DRG_VERIFY_BATCH=32 -fno-unroll-loops -mllvm -amdgpu-sched-strategy=max-ilp")
+    o, e = OracleEngine(_abi.make_config(**kw)), Engine(_abi.make_config(**kw))
+    e.specialize()
+    o.step(600)
+    e.step(600)
+    assert not diff_states(o, e)
+    # opting every engine in through the environment with a bad option: said once on stderr, the generic kernel runs
+    monkeypatch.setenv("RAFTGPU_SPEC_DEFS", "-mllvm -no-such-backend-switch=1")
+    monkeypatch.setenv("RAFTGPU_SPECIALIZE", "1")
+    o, e = OracleEngine(_abi.make_config(**kw)), Engine(_abi.make_config(**kw))
+    o.step(300)
+    e.step(300)
+    assert not diff_states(o, e)
+
+
 def test_bench_workload_specialized_equals_generic():
     """Full size: 65,536 five-peer groups, the benchmark's 20,000 ticks, every group's digest."""
     from raft_amd import Engine
