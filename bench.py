@@ -10,7 +10,8 @@ logs, seeded 10 % request loss + 10 % reply loss, rolling partitions every
 100..119 ticks, one client Start per group every 5 ticks up to 1000 entries,
 20,000 ticks.  Rank r owns global groups [r*65536, (r+1)*65536); the seeded
 streams key on the global group id, so results do not depend on N.  The only
-collective is one all-reduce of counters and safety flags per step.
+collective is one all-reduce of counters and safety summary per step, made
+inside the library (rg_allreduce_summary: ncclAllReduce over xGMI).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -77,11 +78,33 @@ def launch_ranks(n, script=None, argv=None, check_devices=True):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    # rank 0's pipe is read on a thread of its own, so that this loop can watch every child: a rank that dies early
+    # would otherwise leave the others waiting in their rendezvous or a collective until its timeout
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if bad:
+            failed = abs(bad[0])
+            for p in procs:                       # fresh children of this process: no re-exec, plain termination
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.05)
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=30))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return failed or max(abs(rc) for rc in rcs)
 
 
 def cpu_baseline(args, eng):
@@ -178,7 +201,14 @@ def main():
         except Exception as err:      # hiprtc missing: the generic kernel runs, and the line says so
             sys.stderr.write("bench: rg_specialize failed (%s); running the generic kernel\n" % err)
     launch = args.launch_ticks or args.ticks
-    from raft_amd.distributed import all_reduce_summary
+    from raft_amd.distributed import all_reduce_words, flags_of, join_comm
+    # The job's one collective: rg_allreduce_summary (ncclAllReduce inside the library, on the engine's stream) over a
+    # communicator of all ranks; torch.distributed only carries the 128-byte id to the ranks.  Ranks that cannot form an
+    # RCCL communicator (the one-GPU rehearsal) sum the same packed words over torch.distributed instead.
+    in_library = world > 1 and not args.rehearse_on_one_gpu and join_comm(eng, red_dev)
+    collective = ("none (one rank)" if world == 1 else
+                  "rg_allreduce_summary: one ncclAllReduce (RCCL) of %d uint64 per step, in the library" % (_abi.N_COUNTERS + _abi.N_SUMMARY) if in_library else
+                  "torch.distributed all_reduce (%s) of the library's packed words" % dist.get_backend())
 
     def barrier():
         if world > 1:
@@ -192,9 +222,9 @@ def main():
             n = min(launch, args.ticks - done)
             eng.step(n)
             done += n
-        # counters and safety flags: the only cross-GPU exchange of the path
-        fl, nfl = eng.safety_flags()
-        return all_reduce_summary(eng.counters(), fl, nfl, red_dev)
+        # counters and safety summary: the only cross-GPU exchange of the path
+        words = eng.allreduce_summary()              # reduced over the ranks when the engine has a communicator
+        return words if in_library else all_reduce_words(*words, red_dev)
 
     for _ in range(args.warmup):
         one_step()
@@ -211,7 +241,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    counters, flags, flagged_groups = tot
+    counters, summary = tot
+    flags, flagged_groups = flags_of(summary)
     group_ticks_per_step = world * args.groups * args.ticks
 
     # roofline of the tick kernel on this rank: algorithmic bytes of one launch
@@ -235,6 +266,24 @@ def main():
         except Exception:
             traffic = None
 
+    # What actually bounds the fused kernel is instruction issue, not memory: VALU wave-instructions per launch (from a
+    # rocprofv3 --pmc pass of this same command, like the traffic) x 4 cycles each on one of 1,024 SIMDs, at the shader
+    # clock measured in that pass, over this run's kernel time.
+    issue = None
+    pmi = os.path.join(ROOT, "profiles", "pmc_issue.json")
+    if os.path.exists(pmi) and launch == 20000 and args.groups == 65536 and args.peers == 5 and specialized:
+        try:
+            rec = json.load(open(pmi))
+            valu, mhz = float(rec["SQ_INSTS_VALU_per_launch"]), float(rec["shader_clock_mhz"])
+            floor_ms = valu * 4.0 / (1024 * mhz * 1e6) * 1e3
+            issue = {"valu_wave_insts_per_launch": valu, "cycles_per_inst": 4, "simds": 1024, "shader_clock_mhz": mhz,
+                     "issue_floor_ms": floor_ms, "frac": floor_ms / kernel_ms,
+                     "valu_busy_frac_of_simd_cycles": rec.get("valu_busy_frac"), "exec_mask_occupancy": rec.get("exec_mask_occupancy"),
+                     "source": "profiles/pmc_issue.json (%s): counters not measured in this run, kernel_ms is" % rec.get("collected", "rocprofv3 --pmc passes of this command")}
+        except Exception:
+            issue = None
+    fused = launch > 1
+
     out = {
         "metric": "group_ticks_per_sec", "value": group_ticks_per_step * args.steps / dt, "unit": "group-ticks/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -247,10 +296,15 @@ def main():
                             args.part_period + 19, args.entries, args.ticks),
             "groups_total": world * args.groups, "peers": args.peers, "ticks_per_step": args.ticks,
             "ticks_per_launch": launch, "parallelism": "groups sharded x%d, no data-path collective" % world, "seed": args.seed,
+            "collective": collective,
             "kernel_build": "compiled at engine set-up for this configuration (rg_specialize)" if specialized else "generic, precompiled",
         },
         "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # achieved / peak / frac: the byte model (algorithmic bytes per launch over the kernel's time against HBM
+            # peak).  In fused mode 85 % of those bytes -- the per-tick floor -- never move, so the model can exceed
+            # what a streaming kernel reaches and does not name the limiter: `bound` does (VALU issue, see `issue`).
+            "bound": "valu_issue" if fused else "launch_latency", "model_bound": "hbm", "issue": issue,
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source,
             "kernel": "k_tick_spec" if specialized else "k_tick", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
             # the two parts of the algorithmic figure: the per-tick floor (40 B x peers x group-ticks), which a fused
@@ -264,6 +318,18 @@ def main():
                     else "streamed: every peer's state is loaded and stored once per tick",
         },
         "safety_flags": flags, "flagged_groups": flagged_groups,
+        # the flags are raised by the reference's own rules under partitions (tests/test_repaired_rules.py: with its vote
+        # rule, persisted prefix and `restart` repaired the same schedule ends with none); per bit, and how much of the
+        # run's work happened in flagged groups
+        "safety": {
+            "flagged_groups_by_bit": {n: summary["groups_" + n] for n in _abi.FLAG_NAMES},
+            "flagged_groups": flagged_groups, "groups_total": world * args.groups,
+            "share_of_groups": flagged_groups / float(world * args.groups),
+            "share_of_rounds_sent": summary["rounds_flagged"] / float(max(1, summary["rounds_all"])),
+            "share_of_entries_recorded": summary["recorded_flagged"] / float(max(1, summary["recorded_all"])),
+            "note": "rounds = RequestVote + AppendEntries rounds (each up to peers-1 Calls); entries recorded = highest index a "
+                    "group's tester saw applied; a group counts as flagged from the tick its first flag rises to the end of the run",
+        },
         "counters_per_step": counters,
     }
     if args.rehearse_on_one_gpu:

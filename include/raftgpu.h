@@ -139,6 +139,11 @@ enum {
 #define RG_START_ONE  0  /* first connected peer, in index order, that accepts (config.go:436-451) */
 #define RG_START_ALL  1  /* every live peer that claims leadership (test_test.go:697-703)          */
 
+/* ---- log layouts (rg_config.log_layout) ---------------------------------- */
+#define RG_LOG_AUTO    0
+#define RG_LOG_ROWS    1  /* entry i of all peers of a group in one row: replication and apply of index i touch one line */
+#define RG_LOG_COLUMNS 2  /* per-peer contiguous term[] and command[] arrays: replays, catch-up copies and conflict walks stream */
+
 /* Engine configuration: one plain struct across the ABI. */
 typedef struct rg_config {
   int32_t  n_groups;            /* groups owned by this engine (this GPU's shard)                 */
@@ -171,7 +176,10 @@ typedef struct rg_config {
    * engine keeps no ring (device-generated workloads, whose tester side runs on the device).  16 bytes per
    * message, n_groups x n_peers x apply_ring_cap messages of device memory. */
   int32_t  apply_ring_cap;
-  int32_t  reserved[1];
+  /* how the logs lie in device memory (no effect on any result): RG_LOG_AUTO picks columns for logs of 2,048 entries
+   * or more and for engines with crash / restart churn (restarted peers replay their whole log, raft.go:717 with
+   * :672-688), rows otherwise */
+  int32_t  log_layout;
 } rg_config;
 
 typedef struct rg_engine rg_engine;

@@ -56,6 +56,7 @@ FIELDS.update({
     "applyrec": (72, "r64"),
 })
 START_ONE, START_ALL = 0, 1
+LOG_AUTO, LOG_ROWS, LOG_COLUMNS = 0, 1, 2
 
 # scenario schedule ops and selectors
 (OP_CONNECT, OP_DISCONNECT, OP_CRASH, OP_RESTART, OP_START, OP_START_ANY, OP_START_ALL, OP_PICK_LEADER, OP_PICK_RANDOM,
@@ -76,11 +77,11 @@ class Config(C.Structure):
         ("part_period", C.c_int32), ("part_jitter", C.c_int32),
         ("churn_period", C.c_int32), ("churn_disconnect_permille", C.c_int32),
         ("churn_restart_permille", C.c_int32), ("churn_crash_permille", C.c_int32),
-        ("account_bytes", C.c_int32), ("apply_ring_cap", C.c_int32), ("reserved", C.c_int32 * 1),
+        ("account_bytes", C.c_int32), ("apply_ring_cap", C.c_int32), ("log_layout", C.c_int32),
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class VoteArgs(C.Structure):

@@ -74,6 +74,8 @@ static int scratch_of(int device, int **out) {
 struct rg_engine {
   rg_config cfg;
   int G, P, L, PP, Gpad, gpb, rowBytes, cmdOff;
+  bool cols;            // log layout: per-peer columns instead of rows (rg_state.h, Rows)
+  size_t groupBytes;    // bytes of one group's log in either layout
   int slotWaves;        // wavefronts of the tick kernel the device holds at once
   int tickBlocks;       // grid of a plain launch of the tick kernel (DevCfg::nbA blocks of gwA groups per wave, then blocks of gwB)
   int relaySets, relayGw;   // sets of a relay launch and groups per wave in them; 0 when the groups fit the chip at once
@@ -111,6 +113,16 @@ struct rg_engine {
   void *comm;                     // ncclComm_t made by rg_comm_init, or null
 };
 
+// byte offset of entry i of peer p from the first byte of its group's log, in the engine's layout (rg_state.h, Rows)
+static inline size_t host_toff(const rg_engine *e, int i, int p) {
+  return e->cols ? ((size_t)p * e->L + i) * 4 : (size_t)i * e->rowBytes + 4 * (size_t)p;
+}
+static inline size_t host_coff(const rg_engine *e, int i, int p) {
+  return (size_t)e->cmdOff + (e->cols ? ((size_t)p * e->L + i) * 8 : (size_t)i * e->rowBytes + 8 * (size_t)p);
+}
+// bytes from the group's first byte that hold its entries [0, n)
+static inline size_t host_span(const rg_engine *e, int n) { return e->cols ? e->groupBytes : (size_t)n * e->rowBytes; }
+
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { return RG_ERR_HIP; } } while (0)
 
 static const char *kVersion = "raftgpu 0.1 (gfx950)";
@@ -143,6 +155,7 @@ extern "C" int rg_device_count(void) {
 
 static bool valid_config(const rg_config *c) {
   if (!c) return false;
+  if (c->log_layout < RG_LOG_AUTO || c->log_layout > RG_LOG_COLUMNS) return false;
   if (c->n_groups < 1 || c->n_peers < 2 || c->n_peers > RG_MAX_PEERS || c->log_cap < 2) return false;
   if (c->start_period < 0 || c->part_period < 0 || c->churn_period < 0) return false;
   if (c->start_period > 0 && (c->start_max < 0 || c->start_max + 1 > c->log_cap)) return false;
@@ -172,6 +185,7 @@ static void fill_net(rg_engine *e) {
 static void fill_devcfg(rg_engine *e) {
   DevCfg &d = e->dc; const rg_config &c = e->cfg;
   d.G = e->G; d.P = e->P; d.L = e->L; d.rowBytes = e->rowBytes; d.cmdOff = e->cmdOff;
+  d.cols = e->cols ? 1 : 0; d.groupBytes = (int)e->groupBytes;
   d.groupBase = c.group_base; d.seedKey = sm64(c.seed);
   fill_net(e);
   d.startPeriod = c.start_period; d.startFirst = c.start_first_tick; d.startMax = c.start_max; d.startMode = c.start_mode;
@@ -207,7 +221,7 @@ static void fill_devcfg(rg_engine *e) {
     for (int gw = gwMax; gw >= gwMax - 1 && gw >= 1; gw--) {
       const long long gs = 4 * gw;                               // groups per set
       const bool whole = gs * e->PP * 4 % 128 == 0 && gs * e->PP * e->PP * 4 % 128 == 0 &&
-                         gs * e->L * e->rowBytes % 128 == 0 && gs * e->L * 8 % 128 == 0 &&
+                         gs * (long long)e->groupBytes % 128 == 0 && gs * e->L * 8 % 128 == 0 &&
                          gs * e->P * (long long)sizeof(rg_apply_msg) * e->applyCap % 128 == 0;
       if (whole) { e->relayGw = gw; e->relaySets = (int)((e->G + gs - 1) / gs); break; }
     }
@@ -221,8 +235,8 @@ static int init_state(rg_engine *e) {
   hipStream_t st = e->stream;
   hipLaunchKernelGGL(k_init, dim3((unsigned)((nL + 255) / 256)), dim3(256), 0, st, S, e->dc, e->PP, nL);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemsetAsync(S.logRows, 0, (size_t)e->G * e->L * e->rowBytes, st));
-  if (S.snapRows) HIPCHK(hipMemsetAsync(S.snapRows, 0, (size_t)e->G * e->L * e->rowBytes, st));
+  HIPCHK(hipMemsetAsync(S.logRows, 0, (size_t)e->G * e->groupBytes, st));
+  if (S.snapRows) HIPCHK(hipMemsetAsync(S.snapRows, 0, (size_t)e->G * e->groupBytes, st));
   HIPCHK(hipMemsetAsync(S.applyRec, 0, (size_t)e->G * e->L * 8, st));
   HIPCHK(hipMemsetAsync(S.counters, 0, RG_CTR_SLOTS * 8, st));
   HIPCHK(hipMemsetAsync(S.flagSummary, 0, 8, st));
@@ -251,7 +265,7 @@ static void free_engine(rg_engine *e) {
 // host write to the log arrays.
 static int ensure_snap_rows(rg_engine *e) {
   if (e->S.snapRows) return RG_OK;
-  const size_t n = (size_t)e->G * e->L * e->rowBytes;
+  const size_t n = (size_t)e->G * e->groupBytes;
   int rc = dalloc(e, &e->S.snapRows, n);
   if (rc != RG_OK) return rc;
   HIPCHK(hipMemsetAsync(e->S.snapRows, 0, n, e->stream));
@@ -282,6 +296,14 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   e->nLanes = (long long)e->Gpad * e->PP;
   e->cmdOff = (e->P * 4 + 7) & ~7;
   e->rowBytes = (e->cmdOff + e->P * 8 + 15) & ~15;
+  e->groupBytes = (size_t)e->L * e->rowBytes;
+  // Log layout (rg_state.h, Rows).  Rows serve short logs under steady replication; logs that are replayed whole
+  // (restarts of the crash / restart churn, raft.go:717 with :672-688) or walked far (long logs) are per-peer columns.
+  e->cols = cfg->log_layout == RG_LOG_COLUMNS || (cfg->log_layout == RG_LOG_AUTO && (cfg->log_cap >= 2048 || cfg->churn_period > 0));
+  if (e->cols) {
+    e->cmdOff = (e->P * e->L * 4 + 15) & ~15;               // the commands follow the P term arrays
+    e->groupBytes = ((size_t)e->cmdOff + (size_t)e->P * e->L * 8 + 15) & ~(size_t)15;
+  }
   e->ownStream = nullptr; e->dCmd = nullptr; e->hCmd = nullptr; e->dCmdCap = 0; e->cmdEpoch = 0; e->stepMs = 0; e->launches = 0;
   if (hipStreamCreateWithFlags(&e->ownStream, hipStreamNonBlocking) != hipSuccess) { delete e; return RG_ERR_HIP; }
   e->stream = e->ownStream;
@@ -294,7 +316,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (rc == RG_OK) rc = dalloc(e, &S.applyHash, (size_t)e->nLanes);
   if (rc == RG_OK) rc = dalloc(e, &S.nextIdx, (size_t)e->Gpad * e->PP * e->PP);
   if (rc == RG_OK) rc = dalloc(e, &S.matchIdx, (size_t)e->Gpad * e->PP * e->PP);
-  if (rc == RG_OK) rc = dalloc(e, &S.logRows, (size_t)e->G * e->L * e->rowBytes);
+  if (rc == RG_OK) rc = dalloc(e, &S.logRows, (size_t)e->G * e->groupBytes);
   S.snapRows = nullptr;     // allocated when a blob is first imported (ensure_snap_rows)
   if (rc == RG_OK) rc = dalloc(e, &S.applyRec, (size_t)e->G * e->L);
   if (rc == RG_OK) rc = dalloc(e, &S.startSeq, (size_t)e->Gpad);
@@ -451,7 +473,7 @@ static const Rtc *rtc() {
 
 // the fields of DevCfg a specialised kernel has as constants
 static bool spec_same(const DevCfg &a, const DevCfg &b) {
-  return a.P == b.P && a.L == b.L && a.rowBytes == b.rowBytes && a.cmdOff == b.cmdOff && a.reqDrop == b.reqDrop && a.replyDrop == b.replyDrop &&
+  return a.P == b.P && a.L == b.L && a.rowBytes == b.rowBytes && a.cmdOff == b.cmdOff && a.cols == b.cols && a.groupBytes == b.groupBytes && a.reqDrop == b.reqDrop && a.replyDrop == b.replyDrop &&
          a.replyDelay == b.replyDelay && a.startPeriod == b.startPeriod && a.startFirst == b.startFirst && a.startMax == b.startMax &&
          a.startMode == b.startMode && a.partPeriod == b.partPeriod && a.partJitter == b.partJitter && a.churnPeriod == b.churnPeriod &&
          a.churnDisc == b.churnDisc && a.churnRestart == b.churnRestart && a.churnCrash == b.churnCrash && a.acctBytes == b.acctBytes;
@@ -552,7 +574,7 @@ static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
   arch = "--offload-arch=" + arch.substr(0, arch.find(':'));
   std::vector<std::string> opts = {arch, "-O3", "-std=c++17", "-Wno-unused-value"};
   auto def = [&](const char *name, long long v) { opts.push_back(std::string("-DRG_SPEC_") + name + "=" + std::to_string(v)); };
-  def("P", c.P); def("EXT", ext); def("LEAN", lean); def("L", c.L); def("ROWBYTES", c.rowBytes); def("CMDOFF", c.cmdOff);
+  def("P", c.P); def("EXT", ext); def("LEAN", lean); def("L", c.L); def("ROWBYTES", c.rowBytes); def("CMDOFF", c.cmdOff); def("COLS", c.cols); def("GROUPBYTES", c.groupBytes);
   def("REQDROP", c.reqDrop); def("REPLYDROP", c.replyDrop); def("REPLYDELAY", c.replyDelay);
   def("STARTPERIOD", c.startPeriod); def("STARTFIRST", c.startFirst); def("STARTMAX", c.startMax); def("STARTMODE", c.startMode);
   def("PARTPERIOD", c.partPeriod); def("PARTJITTER", c.partJitter);
@@ -611,10 +633,11 @@ static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage,
       return RG_OK;
     }
   }
-#define TICK_LAUNCH(PEERS) do { \
-    if (ext) hipLaunchKernelGGL((k_tick<PEERS, true, false>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
-    else if (lean) hipLaunchKernelGGL((k_tick<PEERS, false, true>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
-    else hipLaunchKernelGGL((k_tick<PEERS, false, false>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)
+#define TICK_LAUNCH2(PEERS, COLS) do { \
+    if (ext) hipLaunchKernelGGL((k_tick<PEERS, true, false, COLS>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
+    else if (lean) hipLaunchKernelGGL((k_tick<PEERS, false, true, COLS>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
+    else hipLaunchKernelGGL((k_tick<PEERS, false, false, COLS>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)
+#define TICK_LAUNCH(PEERS) do { if (e->cols) TICK_LAUNCH2(PEERS, true); else TICK_LAUNCH2(PEERS, false); } while (0)
   switch (e->P) {
   case 2: TICK_LAUNCH(2); break;
   case 3: TICK_LAUNCH(3); break;
@@ -624,6 +647,7 @@ static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage,
   case 7: TICK_LAUNCH(7); break;
   default: TICK_LAUNCH(8); break;
   }
+#undef TICK_LAUNCH2
 #undef TICK_LAUNCH
   HIPCHK(hipGetLastError());
   return RG_OK;
@@ -1020,15 +1044,15 @@ extern "C" int rg_snapshot_export(rg_engine *e, int32_t g, int32_t p, void *buf,
   int32_t *h = (int32_t *)buf;
   h[0] = hdr[0]; h[1] = hdr[1]; h[2] = n; h[3] = 0;
   if (n > 0) {
-    std::vector<char> rows((size_t)n * e->rowBytes);
+    std::vector<char> rows(host_span(e, n));
     const char *srcRows = (((unsigned)flags & F_SNAPEXT) && e->S.snapRows) ? e->S.snapRows : e->S.logRows;
-    rc = d2h(e, rows.data(), srcRows + (size_t)g * e->L * e->rowBytes, rows.size());
+    rc = d2h(e, rows.data(), srcRows + (size_t)g * e->groupBytes, rows.size());
     if (rc != RG_OK) return rc;
     for (int i = 0; i < n; i++) {
       char *o = (char *)buf + 16 + 16 * (size_t)i;
-      memcpy(o, rows.data() + (size_t)i * e->rowBytes + 4 * (size_t)p, 4);
+      memcpy(o, rows.data() + host_toff(e, i, p), 4);
       memset(o + 4, 0, 4);
-      memcpy(o + 8, rows.data() + (size_t)i * e->rowBytes + e->cmdOff + 8 * (size_t)p, 8);
+      memcpy(o + 8, rows.data() + host_coff(e, i, p), 8);
     }
   }
   return RG_OK;
@@ -1055,14 +1079,14 @@ extern "C" int rg_snapshot_import(rg_engine *e, int32_t g, int32_t p, const void
   rc = ensure_snap_rows(e);
   if (rc != RG_OK) return rc;
   if (n > 0) {
-    std::vector<char> rows((size_t)n * e->rowBytes);
-    char *dbase = e->S.snapRows + (size_t)g * e->L * e->rowBytes;
+    std::vector<char> rows(host_span(e, n));
+    char *dbase = e->S.snapRows + (size_t)g * e->groupBytes;
     rc = d2h(e, rows.data(), dbase, rows.size());
     if (rc != RG_OK) return rc;
     for (int i = 0; i < n; i++) {
       const char *s = (const char *)buf + 16 + 16 * (size_t)i;
-      memcpy(rows.data() + (size_t)i * e->rowBytes + 4 * (size_t)p, s, 4);
-      memcpy(rows.data() + (size_t)i * e->rowBytes + e->cmdOff + 8 * (size_t)p, s + 8, 8);
+      memcpy(rows.data() + host_toff(e, i, p), s, 4);
+      memcpy(rows.data() + host_coff(e, i, p), s + 8, 8);
     }
     rc = h2d(e, dbase, rows.data(), rows.size());
     if (rc != RG_OK) return rc;
@@ -1305,25 +1329,26 @@ static int rw_state(rg_engine *e, int field, void *buf, int64_t bytes, bool wr) 
     char *dev = (snap && wr) ? e->S.snapRows : e->S.logRows;
     const bool both = snap && !wr && e->S.snapRows != nullptr;   // reading persisted logs: per peer from where they live
     // group-sized chunks keep the staging buffers small
-    const int chunk = std::max(1, (int)std::min<int64_t>(G, (64ll << 20) / ((int64_t)L * e->rowBytes)));
-    std::vector<char> rows((size_t)chunk * L * e->rowBytes), rows2(both ? rows.size() : 0);
+    const size_t gB = e->groupBytes;
+    const int chunk = std::max(1, (int)std::min<int64_t>(G, (64ll << 20) / (int64_t)gB));
+    std::vector<char> rows((size_t)chunk * gB), rows2(both ? rows.size() : 0);
     for (int g0 = 0; g0 < G; g0 += chunk) {
       const int ng = std::min(chunk, G - g0);
-      const size_t nb = (size_t)ng * L * e->rowBytes;
-      rc = d2h(e, rows.data(), dev + (size_t)g0 * L * e->rowBytes, nb);
+      const size_t nb = (size_t)ng * gB;
+      rc = d2h(e, rows.data(), dev + (size_t)g0 * gB, nb);
       if (rc != RG_OK) return rc;
-      if (both) { rc = d2h(e, rows2.data(), e->S.snapRows + (size_t)g0 * L * e->rowBytes, nb); if (rc != RG_OK) return rc; }
+      if (both) { rc = d2h(e, rows2.data(), e->S.snapRows + (size_t)g0 * gB, nb); if (rc != RG_OK) return rc; }
       for (int g = 0; g < ng; g++) for (int p = 0; p < P; p++) {
         const bool ext = both && (((unsigned)flags[(size_t)(g0 + g) * PP + p]) & F_SNAPEXT);
         char *base = ext ? rows2.data() : rows.data();
         for (int i = 0; i < L; i++) {
-          char *row = base + ((size_t)g * L + i) * e->rowBytes;
+          char *grp = base + (size_t)g * gB;
           const size_t hi = ((size_t)(g0 + g) * P + p) * L + i;
-          if (isCmd) { u64 *hv = (u64 *)buf + hi; if (wr) memcpy(row + e->cmdOff + 8 * (size_t)p, hv, 8); else memcpy(hv, row + e->cmdOff + 8 * (size_t)p, 8); }
-          else { int32_t *hv = (int32_t *)buf + hi; if (wr) memcpy(row + 4 * (size_t)p, hv, 4); else memcpy(hv, row + 4 * (size_t)p, 4); }
+          if (isCmd) { u64 *hv = (u64 *)buf + hi; char *w = grp + host_coff(e, i, p); if (wr) memcpy(w, hv, 8); else memcpy(hv, w, 8); }
+          else { int32_t *hv = (int32_t *)buf + hi; char *w = grp + host_toff(e, i, p); if (wr) memcpy(w, hv, 4); else memcpy(hv, w, 4); }
         }
       }
-      if (wr) { rc = h2d(e, dev + (size_t)g0 * L * e->rowBytes, rows.data(), nb); if (rc != RG_OK) return rc; }
+      if (wr) { rc = h2d(e, dev + (size_t)g0 * gB, rows.data(), nb); if (rc != RG_OK) return rc; }
     }
     if (wr) { e->derivedDirty = true; e->syncDirty = true; }
     return RG_OK;

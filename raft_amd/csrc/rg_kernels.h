@@ -163,11 +163,11 @@ __global__ void k_init(DevPtrs S, DevCfg c, int PP, long long nLanes) {
 __global__ void k_reset_groups(DevPtrs S, DevCfg c, int PP, const int *groups, int nowTick) {
   const int g = groups[blockIdx.x];
   if ((int)threadIdx.x < PP) init_lane(S, c, PP, (long long)g * PP + threadIdx.x, nowTick);
-  const size_t rowInts = (size_t)c.L * c.rowBytes / 4;
-  int *lr = (int *)(S.logRows + (size_t)g * c.L * c.rowBytes);
+  const size_t rowInts = group_log_bytes(c) / 4;
+  int *lr = (int *)(S.logRows + (size_t)g * group_log_bytes(c));
   for (size_t i = threadIdx.x; i < rowInts; i += blockDim.x) lr[i] = 0;
   if (S.snapRows) {
-    int *sr = (int *)(S.snapRows + (size_t)g * c.L * c.rowBytes);
+    int *sr = (int *)(S.snapRows + (size_t)g * group_log_bytes(c));
     for (size_t i = threadIdx.x; i < rowInts; i += blockDim.x) sr[i] = 0;
   }
   for (int i = threadIdx.x; i < c.L; i += blockDim.x) S.applyRec[(size_t)g * c.L + i] = 0;

@@ -23,6 +23,7 @@ struct DevPtrs {
 
 struct DevCfg {
   int G, P, L, rowBytes, cmdOff;
+  int cols, groupBytes;          // log layout: 0 = rows (entry i of all peers in one row), 1 = columns (per-peer arrays); bytes of one group's log
   long long groupBase;
   u64 seedKey;                   // sm64(seed)
   int reqDrop, replyDrop, replyDelay;
@@ -159,16 +160,32 @@ struct LaneT {
   }
 };
 
-// Addressing of one group's log rows.
-// base is wave-uniform in the tick kernel (the block's first group), off the lane's
-// 32-bit byte offset from it, so accesses use scalar-base + vector-offset addressing.
+// Addressing of one group's log.  Two layouts, fixed per engine:
+//   rows    -- entry i of ALL peers of the group is one row {int32 term[P]; uint64 cmd[P]} of rowBytes bytes, rows
+//              consecutive in i: replicating entry i to the followers and applying index i touch one line;
+//   columns -- per peer, int32 term[L] then (at cmdOff) uint64 cmd[L], contiguous in i: a replay of one peer's log
+//              (raft.go:672-688 after a restart), a catch-up copy and the conflict walks (raft.go:308-313, 495-502) read
+//              64 consecutive entries per request instead of one word per row.  (Long logs, crash / restart churn.)
+// base is wave-uniform in the tick kernel (the block's first group), off the lane's 32-bit byte offset from it, so
+// accesses use scalar-base + vector-offset addressing.  `cols` is a compile-time constant there (template parameter).
 struct Rows {
-  char *base; unsigned off; int rowBytes, cmdOff;
-  __device__ int *termp(int i, int col) const { return (int *)(base + (size_t)(off + (unsigned)i * (unsigned)rowBytes + (unsigned)col * 4u)); }
-  __device__ u64 *cmdp(int i, int col) const { return (u64 *)(base + (size_t)(off + (unsigned)i * (unsigned)rowBytes + (unsigned)cmdOff + (unsigned)col * 8u)); }
+  char *base; unsigned off; int rowBytes, cmdOff; int L; bool cols;
+  // byte offset of a term / command word from the group's first byte
+  __device__ unsigned toff(int i, int col) const {
+    return cols ? ((unsigned)col * (unsigned)L + (unsigned)i) * 4u : (unsigned)i * (unsigned)rowBytes + (unsigned)col * 4u;
+  }
+  __device__ unsigned coff(int i, int col) const {
+    return (unsigned)cmdOff + (cols ? ((unsigned)col * (unsigned)L + (unsigned)i) * 8u : (unsigned)i * (unsigned)rowBytes + (unsigned)col * 8u);
+  }
+  __device__ int *termp(int i, int col) const { return (int *)(base + (size_t)(off + toff(i, col))); }
+  __device__ u64 *cmdp(int i, int col) const { return (u64 *)(base + (size_t)(off + coff(i, col))); }
+  // the same for another lane's group (offB: that lane's `off`), for loops in which the whole wave serves one lane
+  __device__ int *termp_at(unsigned offB, int i, unsigned col) const { return (int *)(base + (size_t)(offB + toff(i, (int)col))); }
+  __device__ u64 *cmdp_at(unsigned offB, int i, unsigned col) const { return (u64 *)(base + (size_t)(offB + coff(i, (int)col))); }
 };
+__host__ __device__ static inline size_t group_log_bytes(const DevCfg &c) { return c.cols ? (size_t)c.groupBytes : (size_t)c.L * c.rowBytes; }
 __device__ static inline Rows rows_of(char *arr, const DevCfg &c, int g) {
-  Rows r; r.base = arr + (size_t)g * c.L * c.rowBytes; r.off = 0; r.rowBytes = c.rowBytes; r.cmdOff = c.cmdOff; return r;
+  Rows r; r.base = arr + (size_t)g * group_log_bytes(c); r.off = 0; r.rowBytes = c.rowBytes; r.cmdOff = c.cmdOff; r.L = c.L; r.cols = c.cols != 0; return r;
 }
 // the arrays the tick loop itself touches; everything else is read once and written once
 struct HotPtrs {

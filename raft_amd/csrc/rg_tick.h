@@ -152,7 +152,7 @@ __device__ static inline int turn_start(u64 key, int tick, int P) {
 // instantiation for engines without churn and with the first-leader Start mode (the benchmark's), with that code left out
 // (17 instead of 25 spilled registers).  w: the calling wave's counters of the launch.  stIn / stOut: the set's group words as the
 // previous span left them / for the next span, when spans of one launch run on different blocks (else null).
-template <int P, bool EXT, bool LEAN>
+template <int P, bool EXT, bool LEAN, bool COLS>
 __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, const DevCfg &c, const int set, const int t0, const int nticks, WaveCtr *w,
                                           const int *stIn, int *stOut) {
   constexpr int PP = P <= 4 ? 4 : 8;        // stride of a group in the per-peer arrays and matrices in memory
@@ -200,8 +200,9 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   const int gq = g0 + (int)gLoc;
   const long long gl = (long long)(G.inWave ? g : g0) * PP + (G.inWave ? peer : 0);   // slot in the per-peer arrays
   Rows lg, sn;
-  lg.base = H.logRows + (size_t)g0 * L * c.rowBytes; lg.off = gLoc * (unsigned)L * (unsigned)c.rowBytes; lg.rowBytes = c.rowBytes; lg.cmdOff = c.cmdOff;
-  sn = lg; sn.base = H.snapRows + (size_t)g0 * L * c.rowBytes;
+  const unsigned groupBytes = COLS ? (unsigned)c.groupBytes : (unsigned)L * (unsigned)c.rowBytes;
+  lg.base = H.logRows + (size_t)g0 * groupBytes; lg.off = gLoc * groupBytes; lg.rowBytes = c.rowBytes; lg.cmdOff = c.cmdOff; lg.L = L; lg.cols = COLS;
+  sn = lg; sn.base = H.snapRows + (size_t)g0 * groupBytes;
   int *const nextBlk = H.nextIdx + (size_t)g0 * PP * PP;       // uniform; rows [group][owner][j]
   int *const matchBlk = H.matchIdx + (size_t)g0 * PP * PP;
   const unsigned mOff = gLoc * (unsigned)(PP * PP);
@@ -386,7 +387,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
         unsigned accLo = 0, accHi = 0;
         for (int j = G.lane; j < n; j += 64) {
           const int i = a + 1 + j, ic = i < L ? i : L - 1;
-          const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
+          const u64 cmd = *lg.cmdp_at(offB, ic, col);
           const u64 seen = recBlk[rOffB + (unsigned)ic];
           differs |= cmd != seen;
           const u64 wd = apply_word(cmd, i);
@@ -877,7 +878,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
                 int base = __builtin_amdgcn_readlane(prev, src) - 1, ci;
                 for (;;) {
                   const int ix = base - G.lane;
-                  const bool stop = ix < 0 || *(int *)(lg.base + (size_t)(offB + (unsigned)ix * (unsigned)lg.rowBytes + col * 4u)) != ct;
+                  const bool stop = ix < 0 || *lg.termp_at(offB, ix, col) != ct;
                   const u64 sm = __builtin_amdgcn_ballot_w64(stop);
                   if (sm) { ci = base - (int)__builtin_ctzll(sm) + 1; break; }
                   base -= 64;
@@ -916,11 +917,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
               const unsigned sCol = (unsigned)__builtin_amdgcn_readlane(sIdx, src), tCol = (unsigned)__builtin_amdgcn_readlane(peer, src);
               const int tTid = (tid & ~63) + src;
               for (int i = nxB + G.lane; i < lenB; i += 64) {
-                char *row = lg.base + (size_t)(offB + (unsigned)i * (unsigned)lg.rowBytes);
-                const int tm = *(int *)(row + sCol * 4u);
-                const u64 cm = *(u64 *)(row + (unsigned)lg.cmdOff + sCol * 8u);
-                *(int *)(row + tCol * 4u) = tm;
-                *(u64 *)(row + (unsigned)lg.cmdOff + tCol * 8u) = cm;
+                const int tm = *lg.termp_at(offB, i, sCol);
+                const u64 cm = *lg.cmdp_at(offB, i, sCol);
+                *lg.termp_at(offB, i, tCol) = tm;
+                *lg.cmdp_at(offB, i, tCol) = cm;
                 if (i >= lenB - RING) { const int q = i & (RING - 1); ringIdx[q][tTid] = i; ringTerm[q][tTid] = tm; ringCmd[q][tTid] = cm; }
               }
             }
@@ -978,7 +978,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
               int base = __builtin_amdgcn_readlane(nx, src) - 1, hit, hitTerm;
               for (;;) {                                 // ends at index 0 at the latest: its term 0 is not above ct
                 const int ix = base - G.lane;
-                const int tmv = ix >= 0 ? *(int *)(lg.base + (size_t)(offB + (unsigned)ix * (unsigned)lg.rowBytes + col * 4u)) : 0;
+                const int tmv = ix >= 0 ? *lg.termp_at(offB, ix, col) : 0;
                 const u64 sm = __builtin_amdgcn_ballot_w64(tmv <= ct);
                 if (sm) { const int f = (int)__builtin_ctzll(sm); hit = base - f; hitTerm = __builtin_amdgcn_readlane(tmv, f); break; }
                 base -= 64;
@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
               const unsigned col = (unsigned)__builtin_amdgcn_readlane(peer, src);
               for (int j = G.lane; j < n; j += 64) {
                 const int i = lo + 1 + j, ic = i < L ? i : L - 1;
-                const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
+                const u64 cmd = *lg.cmdp_at(offB, ic, col);
                 recBlk[rOffB + (unsigned)ic] = cmd;
               }
             } while (sm);
@@ -1122,7 +1122,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
               // same slots, and lanes that write one slot do so in no particular order)
               for (int j = (n > H.applyCap ? n - H.applyCap : 0) + G.lane; j < n; j += 64) {
                 const int i = lo + 1 + j, ic = i < L ? i : L - 1;
-                const u64 cmd = *(u64 *)(lg.base + (size_t)(offB + (unsigned)ic * (unsigned)lg.rowBytes + (unsigned)lg.cmdOff + col * 8u));
+                const u64 cmd = *lg.cmdp_at(offB, ic, col);
                 rg_apply_msg m; m.command_index = i; m.command = cmd;
                 ring[(hd + (unsigned)j) % (unsigned)H.applyCap] = m;
               }
@@ -1225,12 +1225,12 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 // of its own to write back is not known to be refetched for its other bytes: the per-group words travel through
 // a staging area with whole lines per set instead (the host lays out relay launches so that no other array has
 // a line with two sets in it).
-template <int P, bool EXT, bool LEAN>
+template <int P, bool EXT, bool LEAN, bool COLS>
 __device__ __forceinline__ void tick_launch(const DevPtrs *Sp, HotPtrs &H, DevCfg &c, int t0, int nticks) {
 #ifdef RG_SPEC_P
   // A build for one engine's configuration (rg_specialize compiles this file at run time): what rg_create fixed is a
   // compile-time constant here, so it costs no scalar register and folds into the arithmetic around it.
-  c.P = RG_SPEC_P; c.L = RG_SPEC_L; c.rowBytes = RG_SPEC_ROWBYTES; c.cmdOff = RG_SPEC_CMDOFF;
+  c.P = RG_SPEC_P; c.L = RG_SPEC_L; c.rowBytes = RG_SPEC_ROWBYTES; c.cmdOff = RG_SPEC_CMDOFF; c.cols = RG_SPEC_COLS; c.groupBytes = RG_SPEC_GROUPBYTES;
   c.reqDrop = RG_SPEC_REQDROP; c.replyDrop = RG_SPEC_REPLYDROP; c.replyDelay = RG_SPEC_REPLYDELAY;
   c.startPeriod = RG_SPEC_STARTPERIOD; c.startFirst = RG_SPEC_STARTFIRST; c.startMax = RG_SPEC_STARTMAX; c.startMode = RG_SPEC_STARTMODE;
   c.partPeriod = RG_SPEC_PARTPERIOD; c.partJitter = RG_SPEC_PARTJITTER;
@@ -1265,7 +1265,7 @@ __device__ __forceinline__ void tick_launch(const DevPtrs *Sp, HotPtrs &H, DevCf
     }
   }
   __syncthreads();
-  tick_span<P, EXT, LEAN>(Sp, H, c, set, t0, nticks, w, stIn, stOut);
+  tick_span<P, EXT, LEAN, COLS>(Sp, H, c, set, t0, nticks, w, stIn, stOut);
   if (c.relaySets > 0) {
     __syncthreads();                                 // every wave's stores have reached the L2; thread 0's release writes it back
     if (threadIdx.x == 0) {
@@ -1280,12 +1280,12 @@ __device__ __forceinline__ void tick_launch(const DevPtrs *Sp, HotPtrs &H, DevCf
 // (the extended instantiation carries the schedule's and the apply ring's code and is not asked to fit 4 waves per SIMD)
 #ifdef RG_SPEC_P
 extern "C" __global__ __launch_bounds__(256, RG_SPEC_EXT ? 2 : RG_TICK_WAVES) void k_tick_spec(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
-  tick_launch<RG_SPEC_P, RG_SPEC_EXT != 0, RG_SPEC_LEAN != 0>(Sp, H, c, t0, nticks);
+  tick_launch<RG_SPEC_P, RG_SPEC_EXT != 0, RG_SPEC_LEAN != 0, RG_SPEC_COLS != 0>(Sp, H, c, t0, nticks);
 }
 #else
-template <int P, bool EXT, bool LEAN>
+template <int P, bool EXT, bool LEAN, bool COLS>
 __global__ __launch_bounds__(256, EXT ? 2 : RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
-  tick_launch<P, EXT, LEAN>(Sp, H, c, t0, nticks);
+  tick_launch<P, EXT, LEAN, COLS>(Sp, H, c, t0, nticks);
 }
 #endif
 

@@ -28,12 +28,11 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from raft_amd import Engine
-    from raft_amd.distributed import all_reduce_summary, shard_base
+    from raft_amd.distributed import all_reduce_words, shard_base
     e = Engine(_abi.make_config(n_groups=G, group_base=shard_base(rank, G), device=0, **KW))
     e.step(TICKS)
     e.safety_check()
-    fl, nfl = e.safety_flags()
-    res = all_reduce_summary(e.counters(), fl, nfl, torch.device("cpu"))
+    res = all_reduce_words(*e.allreduce_summary(), torch.device("cpu"))     # the engine's packed words (no communicator), summed over gloo
     torch.save((res, e.state_hash().tolist()), "%s.%d" % (out, rank))
     e.close()
     dist.destroy_process_group()
@@ -46,12 +45,14 @@ def test_two_hip_ranks_equal_one_engine(tmp_path):
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     (res0, h0), (res1, h1) = torch.load(out + ".0"), torch.load(out + ".1")
     assert res0 == res1                                   # every rank holds the reduced summary
-    counters, flags, nflagged = res0
+    from raft_amd.distributed import flags_of
+    counters, summary = res0
     whole = Engine(_abi.make_config(n_groups=2 * G, **KW))
     whole.step(TICKS)
     whole.safety_check()
     assert counters == whole.counters()
-    assert (flags, nflagged) == whole.safety_flags()
+    assert summary == whole.safety_summary()
+    assert flags_of(summary) == whole.safety_flags()
     assert h0 + h1 == whole.state_hash().tolist()
 
 
@@ -75,3 +76,5 @@ def test_bench_launches_its_own_ranks():
     e.step(1500)
     assert out["counters_per_step"] == e.counters()
     assert [out["safety_flags"], out["flagged_groups"]] == list(e.safety_flags())
+    assert out["safety"]["flagged_groups_by_bit"] == {n: e.safety_summary()["groups_" + n] for n in _abi.FLAG_NAMES}
+    assert "torch.distributed" in out["config"]["collective"]

@@ -21,12 +21,11 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle.binding import OracleEngine
     from raft_amd import _abi
-    from raft_amd.distributed import all_reduce_summary, shard_base
+    from raft_amd.distributed import all_reduce_words, shard_base
     e = OracleEngine(_abi.make_config(n_groups=G, group_base=shard_base(rank, G), **KW))
     e.step(TICKS)
     e.safety_check()
-    fl, nfl = e.safety_flags()
-    res = all_reduce_summary(e.counters(), fl, nfl, torch.device("cpu"))
+    res = all_reduce_words(e.counters(), e.safety_summary(), torch.device("cpu"))
     if rank == 0:
         torch.save((res, e.state_hash().tolist()), out)
     else:
@@ -40,18 +39,24 @@ def test_two_ranks_equal_one_unsharded_run(tmp_path, oracle_lib):
     out = str(tmp_path / "r0.pt")
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-    (counters, flags, nflagged), h0 = torch.load(out)
+    from raft_amd.distributed import flags_of
+    (counters, summary), h0 = torch.load(out)
     h1 = torch.load(out + ".1")
     whole = OracleEngine(_abi.make_config(n_groups=2 * G, **KW))
     whole.step(TICKS)
     whole.safety_check()
     assert counters == whole.counters()
-    assert (flags, nflagged) == whole.safety_flags()
+    assert summary == whole.safety_summary() and summary["flagged_groups"] > 0
+    assert flags_of(summary) == whole.safety_flags()
     assert h0 + h1 == whole.state_hash().tolist()
 
 
 def test_summary_is_identity_without_process_group():
     from raft_amd import _abi
-    from raft_amd.distributed import all_reduce_summary
+    from raft_amd.distributed import all_reduce_words, flags_of, join_comm
     c = {k: i * 3 for i, k in enumerate(_abi.COUNTERS)}
-    assert all_reduce_summary(c, 0x29, 5, torch.device("cpu")) == (c, 0x29, 5)
+    s = {k: 0 for k in _abi.SUMMARY}
+    s.update(groups_election_safety=4, groups_state_machine=2, groups_ref_panic=1, flagged_groups=5)
+    assert all_reduce_words(c, s) == (c, s)
+    assert flags_of(s) == (0x29, 5)
+    assert join_comm(None) is False
