@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Kernel time of the other named configurations (one rank's share), for the numbers table.
-usage: python profiles/time_configs.py       (GENERIC=1: the precompiled kernel instead of the one rg_specialize builds)"""
+usage: python profiles/time_configs.py       (GENERIC=1: the precompiled kernel instead of the one rg_specialize builds;
+ONLY=cfg4: one configuration; LAYOUT=1 rows / 2 columns: the log layout instead of the one the engine picks)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raft_amd import Engine, _abi
@@ -17,6 +18,9 @@ for name, (kw, T) in CASES.items():
         continue
     if os.environ.get("NGROUPS"):           # tuning aid: the same configuration with another number of groups
         kw = dict(kw, n_groups=int(os.environ["NGROUPS"]))
+    if os.environ.get("LAYOUT"):
+        kw = dict(kw, log_layout=int(os.environ["LAYOUT"]))
+        name += " [layout %s]" % {"1": "rows", "2": "columns"}.get(os.environ["LAYOUT"], "auto")
     e = Engine(_abi.make_config(**kw))
     if not os.environ.get("GENERIC"):
         e.specialize()

@@ -41,14 +41,16 @@ def _same(o, e):
     assert o.safety_check() == e.safety_check()
 
 
+@pytest.mark.parametrize("layout", [_abi.LOG_ROWS, _abi.LOG_COLUMNS])
 @pytest.mark.parametrize("name,kw,groups,ticks", [
     ("cfg2", CFG2, 4096, 10000),
     ("cfg3", CFG3, 3000, 20000),
     ("cfg4", CFG4, 300, 40000),
     ("cfg5", CFG5, 8192, 4000),
 ])
-def test_whole_schedule_reduced(name, kw, groups, ticks):
-    o, e = _oracle(n_groups=groups, **kw), _engine(n_groups=groups, **kw)
+def test_whole_schedule_reduced(name, kw, groups, ticks, layout):
+    """Both log layouts (rows: entry i of all peers together; columns: per-peer arrays) give the oracle's words."""
+    o, e = _oracle(n_groups=groups, **kw), _engine(n_groups=groups, log_layout=layout, **kw)
     half = ticks // 2
     for n in (half, ticks - half):
         o.step_mt(n, 8)
@@ -118,7 +120,14 @@ def test_target_shard_131072x5_every_group():
     assert c["entries_committed"] > 0.7 * 131072 * 1000      # partitions and loss keep some groups from finishing
 
 
-def test_cfg4_full_size_every_group():
-    """16,384 seven-peer groups, 4096-entry logs, crash / restart churn."""
-    e = _every_group(CFG4, 16384, 40000, 2048)
+@pytest.mark.parametrize("layout", [_abi.LOG_ROWS, _abi.LOG_AUTO])
+def test_cfg4_full_size_every_group(layout):
+    """16,384 seven-peer groups, 4096-entry logs, crash / restart churn; with the layout the engine picks for such a
+    configuration (columns) and with rows."""
+    e = _every_group(dict(CFG4, log_layout=layout), 16384, 40000, 2048)
     assert e.counters()["ae_conflicts"] > 0
+
+
+def test_target_shard_in_columns():
+    """The benchmark workload at full size in the layout it does not pick by itself."""
+    _every_group(dict(CFG3, log_layout=_abi.LOG_COLUMNS), 65536, 20000, 8192)

@@ -117,7 +117,8 @@ def _run(seed, tweak=None, until=1500):
     if _ENV.get("RAFT_FUZZ_EXT"):                       # every case on the extended instantiation: byte accounting and an apply ring
         kw["account_bytes"] = 1
         kw.setdefault("apply_ring_cap", 64)
-    o, e = OracleEngine(_abi.make_config(**kw)), Engine(_abi.make_config(**kw))
+    layout = random.Random(31337 + seed).choice([_abi.LOG_AUTO, _abi.LOG_ROWS, _abi.LOG_COLUMNS])   # (its own stream) how the logs lie in memory changes no result
+    o, e = OracleEngine(_abi.make_config(**kw)), Engine(_abi.make_config(log_layout=layout, **kw))
     if random.Random(77 + seed).random() < float(_ENV.get("RAFT_FUZZ_SPECIALIZE", "0.06")):   # (its own stream: the case stays the same)
         e.specialize()                                  # some cases run on a kernel compiled for their configuration
     if rng.random() < p_sched:
