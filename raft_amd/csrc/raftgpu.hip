@@ -71,6 +71,12 @@ static int scratch_of(int device, int **out) {
 }
 
 // ---------------------------------------------------------------- host side
+// Launches of at most this many ticks run only the groups that are due (k_tick_due).  Measured on 65,536 five-peer groups
+// of the benchmark workload, kernel time of a launch of 1 / 2 / 5 / 8 ticks: 108.8 / 131.9 / 156.6 / 175.7 us full, 61.6 /
+// 85.9 / 154.9 / 236.7 us due (a sixth of the groups is due in one tick, half of them in five).
+#ifndef RG_DUE_MAX_TICKS
+#define RG_DUE_MAX_TICKS 4
+#endif
 struct rg_engine {
   rg_config cfg;
   int G, P, L, PP, Gpad, gpb, rowBytes, cmdOff;
@@ -95,6 +101,11 @@ struct rg_engine {
   long long launches;
   long long now;
   bool derivedDirty, syncDirty;
+  // Due launches (k_tick_due): short launches run only the groups whose `wake` word falls inside the launch.
+  bool lazy;            // some groups' stored words lag behind `now` (skipped by a due launch): settle() before reading them
+  bool wakeDirty;       // the host wrote state behind the wake words' back: the next launch is a full one, which rewrites them all
+  int dueWin;           // groups per block window of a due launch
+  int dueMaxTicks;      // launches of at most this many ticks are due launches (0: never)
   std::vector<unsigned> drained;  // per (g,p): ApplyMsgs handed out by rg_drain_applied so far
   rg_apply_msg *applyRing; unsigned *applyHead; int applyCap;
   unsigned *netCfg;               // device: per-group net rates, allocated by the first rg_set_unreliable_group
@@ -212,7 +223,22 @@ static void fill_devcfg(rg_engine *e) {
   if (const char *ov = getenv("RAFTGPU_TAIL_GROUPS_PER_WAVE")) gwB = atoi(ov);   // tuning aid
   d.gwB = gwB < 1 ? 1 : (gwB > gwMax ? gwMax : gwB);
   e->tickBlocks = d.nbA + (rest + 4 * d.gwB - 1) / (4 * d.gwB);
-  d.relaySets = 0; d.relayChunk = 0;
+  d.relaySets = 0; d.relayChunk = 0; d.lazy = 0;
+  // Due launches: one block looks at a window of consecutive groups and runs those that are due, shared out among its waves.
+  // A short launch costs a wave the same whether it holds one group or twelve, so the due groups should fill few waves: the
+  // windows are as large as leaving one block per CU allows (65,536 groups: 256 per block, of which about 40 are due in a
+  // one-tick launch of the benchmark workload), 256 at most.
+  {
+    const int cus = std::max(1, e->slotWaves / (4 * RG_TICK_WAVES));
+    long long win = ((long long)e->G + cus - 1) / cus;
+    if (const char *ov = getenv("RAFTGPU_DUE_WIN")) win = atoi(ov);           // tuning aid
+    e->dueWin = (int)(win < 1 ? 1 : (win > 256 ? 256 : win));
+    d.dueWin = e->dueWin;
+    e->dueMaxTicks = RG_DUE_MAX_TICKS;
+    if (const char *ov = getenv("RAFTGPU_DUE_MAX_TICKS")) e->dueMaxTicks = atoi(ov);   // tuning / test aid; 0: every launch is a full one
+    // (the lane offsets of a window must fit 32 bits)
+    if ((unsigned long long)e->groupBytes * 256ull >= (1ull << 32) || (unsigned long long)e->L * 256ull * 8ull >= (1ull << 32)) e->dueMaxTicks = 0;
+  }
   // More groups than the chip holds at once: long launches go through the relay queue (see k_tick).  There a set's
   // state passes from block to block within a launch, so no 128-byte line of any array may hold words of two
   // sets: the waves of a relay launch hold the most groups for which every array's bytes per set are whole lines.
@@ -245,6 +271,7 @@ static int init_state(rg_engine *e) {
   HIPCHK(hipMemsetAsync(S.schedPos, 0, (size_t)e->Gpad * sizeof(int), st));      // tick 0: the schedule starts over
   HIPCHK(hipStreamSynchronize(st));
   e->now = 0; e->derivedDirty = false; e->syncDirty = false;
+  e->lazy = false; e->wakeDirty = false;           // k_init left every wake word at 0: all groups are looked at
   std::fill(e->drained.begin(), e->drained.end(), 0);
   return RG_OK;
 }
@@ -326,6 +353,8 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (rc == RG_OK) rc = dalloc(e, &S.schedPos, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.schedRegs, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.gflags, (size_t)e->Gpad);
+  if (rc == RG_OK) rc = dalloc(e, &S.wake, (size_t)e->Gpad);
+  if (rc == RG_OK) rc = dalloc(e, &S.settled, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.counters, (size_t)RG_CTR_SLOTS);
   if (rc == RG_OK) rc = dalloc(e, &S.flagSummary, (size_t)2);
   if (rc == RG_OK) rc = dalloc(e, &e->redBuf, (size_t)(RG_N_COUNTERS + RG_N_SUMMARY));
@@ -393,6 +422,7 @@ extern "C" int rg_set_stream(rg_engine *e, void *s) {
 
 static int run_derive(rg_engine *e) {
   if (!e->derivedDirty) return RG_OK;
+  e->wakeDirty = true;                       // k_derive marks every leader's commit rule for evaluation
   int blocks = (int)((e->nLanes + 255) / 256);
   hipLaunchKernelGGL(k_derive, dim3(blocks), dim3(256), 0, e->stream, e->S, e->dc, e->PP, e->syncDirty ? 1 : 0);
   HIPCHK(hipGetLastError());
@@ -607,11 +637,45 @@ static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
 // One launch of the tick kernel.  relay / relayStage: the queue and staging area a relay launch uses.
 // mayCompile: a specialised kernel that no longer fits the configuration may be rebuilt here (never on the path that
 // must not allocate).
-static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage, bool mayCompile) {
+static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage, bool mayCompile, bool forceFull = false) {
   DevCfg dc = e->dc;
   HotPtrs H = e->H;
   H.relay = relay; H.relayStage = relayStage;
   int blocks = e->tickBlocks;
+  const DevPtrs *dS = e->dS;
+  if (!forceFull && !e->wakeDirty && n_ticks > 0 && n_ticks <= e->dueMaxTicks) {
+    // a due launch: the groups with an event inside the launch, found from their wake words by the kernel itself
+    const unsigned dblocks = (unsigned)(((long long)e->G + e->dueWin - 1) / e->dueWin);
+    dc.lazy = e->lazy ? 1 : 0;
+    const bool extD = dc.acctBytes || H.applyCap > 0 || H.netCfg || H.schedN > 0;
+    if (getenv("RAFTGPU_TRACE_LAUNCH")) fprintf(stderr, "raftgpu: k_tick_due ticks=%d blocks=%u window=%d lazy=%d\n", n_ticks, dblocks, e->dueWin, dc.lazy);
+#define DUE_LAUNCH2(PEERS, COLS) do { \
+    if (extD) hipLaunchKernelGGL((k_tick_due<PEERS, true, COLS>), dim3(dblocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
+    else hipLaunchKernelGGL((k_tick_due<PEERS, false, COLS>), dim3(dblocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)
+#define DUE_LAUNCH(PEERS) do { if (e->cols) DUE_LAUNCH2(PEERS, true); else DUE_LAUNCH2(PEERS, false); } while (0)
+#ifdef RG_ONLY_P                                   // diagnostic builds: one peer count, a tenth of the compile time
+    if (e->P != RG_ONLY_P) return RG_ERR_ARG;
+    DUE_LAUNCH(RG_ONLY_P);
+#else
+    switch (e->P) {
+    case 2: DUE_LAUNCH(2); break;
+    case 3: DUE_LAUNCH(3); break;
+    case 4: DUE_LAUNCH(4); break;
+    case 5: DUE_LAUNCH(5); break;
+    case 6: DUE_LAUNCH(6); break;
+    case 7: DUE_LAUNCH(7); break;
+    default: DUE_LAUNCH(8); break;
+    }
+#endif
+#undef DUE_LAUNCH2
+#undef DUE_LAUNCH
+    HIPCHK(hipGetLastError());
+    e->lazy = true;
+    return RG_OK;
+  }
+  // a full launch brings every group up to its end and rewrites every wake word
+  dc.lazy = e->lazy ? 1 : 0;
+  struct Full { rg_engine *e; ~Full() { e->lazy = false; e->wakeDirty = false; } } fullDone{e};
   const int chunk = relay_chunk_ticks(e, n_ticks);
   if (chunk > 0) {
     dc.relaySets = e->relaySets; dc.relayChunk = chunk;
@@ -620,7 +684,6 @@ static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage,
     HIPCHK(hipMemsetAsync(relay, 0, (size_t)(e->relaySets + 1) * sizeof(int), e->stream));
   }
   if (getenv("RAFTGPU_TRACE_LAUNCH")) fprintf(stderr, "raftgpu: k_tick ticks=%d blocks=%d relay_sets=%d relay_chunk=%d groups_per_wave=%d\n", n_ticks, blocks, dc.relaySets, dc.relayChunk, dc.gwA);
-  const DevPtrs *dS = e->dS;
   const bool lean = dc.churnPeriod == 0 && dc.startMode == RG_START_ONE;     // nothing the lean instantiation leaves out is in use
   const bool ext = dc.acctBytes || H.applyCap > 0 || H.netCfg || H.schedN > 0;
   if (e->specWanted) {
@@ -638,6 +701,10 @@ static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage,
     else if (lean) hipLaunchKernelGGL((k_tick<PEERS, false, true, COLS>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
     else hipLaunchKernelGGL((k_tick<PEERS, false, false, COLS>), dim3(blocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)
 #define TICK_LAUNCH(PEERS) do { if (e->cols) TICK_LAUNCH2(PEERS, true); else TICK_LAUNCH2(PEERS, false); } while (0)
+#ifdef RG_ONLY_P
+  if (e->P != RG_ONLY_P) return RG_ERR_ARG;
+  TICK_LAUNCH(RG_ONLY_P);
+#else
   switch (e->P) {
   case 2: TICK_LAUNCH(2); break;
   case 3: TICK_LAUNCH(3); break;
@@ -647,11 +714,26 @@ static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage,
   case 7: TICK_LAUNCH(7); break;
   default: TICK_LAUNCH(8); break;
   }
+#endif
 #undef TICK_LAUNCH2
 #undef TICK_LAUNCH
   HIPCHK(hipGetLastError());
   return RG_OK;
 }
+
+// After due launches the stored words of the groups they skipped lag behind `now`: their election-loop and monitor
+// wake-up chains, and the client Starts of an engine with a device client, wait for the group's next span.  A full
+// launch of zero ticks carries all of that out (the end of every span does), so that what the host then reads is what
+// tick-by-tick execution leaves.
+static int settle(rg_engine *e) {
+  if (!e->lazy) return RG_OK;
+  int rc = run_derive(e);
+  if (rc != RG_OK) return rc;
+  return launch_kernel(e, 0, e->relay, e->relayStage, false, true);
+}
+// The same where only pending client Starts matter (they write logs, persisted headers, counters and the overflow flag; the
+// wake-up chains are times nobody but the tick kernel looks at).
+static int settle_client(rg_engine *e) { return e->dc.startPeriod > 0 ? settle(e) : RG_OK; }
 
 static int launch_ticks(rg_engine *e, int n_ticks) {
   hipEvent_t a, b;
@@ -794,7 +876,8 @@ static int run_staged_cmds(rg_engine *e, size_t n) {
   if (n == 0) return RG_OK;
   HostCmd *cmds = e->hCmd;
   for (size_t i = 0; i < n; i++) if (cmds[i].group < 0 || cmds[i].group >= e->G || cmds[i].peer < 0 || cmds[i].peer >= e->P) return RG_ERR_RANGE;
-  int rc = run_derive(e);
+  int rc = settle_client(e);           // host verbs neither read nor write the lazy wake-up times (make_peer overwrites them)
+  if (rc == RG_OK) rc = run_derive(e);
   if (rc != RG_OK) return rc;
   std::vector<int> level;
   const int maxLevel = batch_levels(e, &cmds[0].group, sizeof(HostCmd) / sizeof(int32_t), n, level);
@@ -932,6 +1015,8 @@ extern "C" int rg_set_schedule(rg_engine *e, const rg_sched_op *ops, int64_t n) 
     const bool isReg = ops[i].op == RG_OP_START_ALL || (ops[i].op >= RG_OP_PICK_LEADER && ops[i].op <= RG_OP_PICK_OTHER);
     if (isReg ? (a < 0 || a > 3) : !((a >= 0 && a < e->P) || a == RG_SEL_ALL || ((a & ~0x3F) == 0x100 && (a & 15) < e->P)) && ops[i].op != RG_OP_START_ANY) return RG_ERR_ARG;
   }
+  { int rs = settle(e); if (rs != RG_OK) return rs; }
+  e->wakeDirty = true;                               // the schedule's ticks are events
   HIPCHK(hipStreamSynchronize(e->stream));
   e->H.sched = nullptr; e->H.schedN = 0; e->schedN = 0;
   e->schedHost.assign(ops, ops + n);
@@ -1026,6 +1111,7 @@ extern "C" int rg_drain_applied(rg_engine *e, int32_t g, int32_t p, rg_apply_msg
 extern "C" int rg_snapshot_export(rg_engine *e, int32_t g, int32_t p, void *buf, int64_t cap, int64_t *size_out) {
   LOCK(e);
   if (g < 0 || g >= e->G || p < 0 || p >= e->P) return RG_ERR_RANGE;
+  { int rs = settle_client(e); if (rs != RG_OK) return rs; }
   const size_t gl = (size_t)g * e->PP + p;
   int flags = 0, hdr[3];
   HIPCHK(hipMemcpyAsync(&flags, e->S.flags + gl, 4, hipMemcpyDeviceToHost, e->stream));     // four words, one wait
@@ -1063,7 +1149,10 @@ extern "C" int rg_snapshot_import(rg_engine *e, int32_t g, int32_t p, const void
   if (g < 0 || g >= e->G || p < 0 || p >= e->P) return RG_ERR_RANGE;
   const size_t gl = (size_t)g * e->PP + p;
   int flags = 0;
-  int rc = d2h(e, &flags, e->S.flags + gl, 4);
+  int rc = settle(e);
+  if (rc != RG_OK) return rc;
+  e->wakeDirty = true;
+  rc = d2h(e, &flags, e->S.flags + gl, 4);
   if (rc != RG_OK) return rc;
   if (size == 0) {
     flags &= ~(int)F_SNAPHAS;
@@ -1120,7 +1209,8 @@ extern "C" int rg_rpc_request_vote(rg_engine *e, int64_t n, const int32_t *group
   if (n < 0 || (n > 0 && (!groups || !peers || !args || !replies))) return RG_ERR_ARG;
   if (n == 0) return RG_OK;
   for (int64_t i = 0; i < n; i++) if (groups[i] < 0 || groups[i] >= e->G || peers[i] < 0 || peers[i] >= e->P) return RG_ERR_RANGE;
-  int rc = run_derive(e);
+  int rc = settle(e);
+  if (rc == RG_OK) rc = run_derive(e);
   if (rc != RG_OK) return rc;
   std::vector<int> order; std::vector<size_t> startOf;
   level_order(e, groups, n, order, startOf);
@@ -1156,7 +1246,8 @@ extern "C" int rg_rpc_append_entries(rg_engine *e, int64_t n, const int32_t *gro
     if (a.prev_log_index < 0 || a.n_entries < 0 || (int64_t)a.prev_log_index + 1 + a.n_entries > e->L) return RG_ERR_RANGE;
     if (a.entry_off < 0 || a.entry_off + a.n_entries > ne) return RG_ERR_RANGE;
   }
-  int rc = run_derive(e);
+  int rc = settle(e);
+  if (rc == RG_OK) rc = run_derive(e);
   if (rc != RG_OK) return rc;
   std::vector<int> order; std::vector<size_t> startOf;
   level_order(e, groups, n, order, startOf);
@@ -1241,6 +1332,8 @@ static int *group_word(rg_engine *e, int field) {
 
 static int rw_state(rg_engine *e, int field, void *buf, int64_t bytes, bool wr) {
   if (!buf) return RG_ERR_ARG;
+  { int rs = settle(e); if (rs != RG_OK) return rs; }
+  if (wr) e->wakeDirty = true;
   if (field >= RG_F_CACHE_LASTTERM && field <= RG_F_CACHE_COMMITTERM) {
     if (wr || bytes != (int64_t)e->G * e->P * 4) return RG_ERR_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1372,6 +1465,7 @@ extern "C" int rg_write_state(rg_engine *e, int32_t field, const void *src, int6
 extern "C" int rg_state_hash(rg_engine *e, uint64_t *out, int64_t n) {
   LOCK(e);
   if (!out || n != e->G) return RG_ERR_ARG;
+  { int rs = settle(e); if (rs != RG_OK) return rs; }
   TmpBuf tb;
   u64 *d = tb.get<u64>((size_t)e->G);
   if (!d) return RG_ERR_NOMEM;
@@ -1385,7 +1479,8 @@ extern "C" int rg_state_hash(rg_engine *e, uint64_t *out, int64_t n) {
 extern "C" int rg_counters(rg_engine *e, uint64_t *out) {
   LOCK(e);
   if (!out) return RG_ERR_ARG;
-  int rc = d2h(e, out, e->S.counters, RG_N_COUNTERS * 8);
+  int rc = settle_client(e);
+  if (rc == RG_OK) rc = d2h(e, out, e->S.counters, RG_N_COUNTERS * 8);
   if (rc != RG_OK) return rc;
   out[RG_C_GROUP_TICKS] = (uint64_t)e->G * (uint64_t)e->now;
   return RG_OK;
@@ -1403,6 +1498,7 @@ extern "C" int rg_rpc_bytes(rg_engine *e, int64_t command_bytes, uint64_t *total
 
 extern "C" int rg_safety_check(rg_engine *e) {
   LOCK(e);
+  { int rs = settle_client(e); if (rs != RG_OK) return rs; }
   const long long n = (long long)e->G * e->L;
   hipLaunchKernelGGL(k_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->S, e->dc, e->PP);
   HIPCHK(hipGetLastError());
@@ -1413,6 +1509,7 @@ extern "C" int rg_safety_check(rg_engine *e) {
 extern "C" int rg_safety_flags(rg_engine *e, uint32_t *out) {
   LOCK(e);
   if (!out) return RG_ERR_ARG;
+  { int rs = settle_client(e); if (rs != RG_OK) return rs; }
   HIPCHK(hipMemsetAsync(e->S.flagSummary, 0, 8, e->stream));
   hipLaunchKernelGGL(k_flag_summary, dim3((e->G + 255) / 256), dim3(256), 0, e->stream, e->S, e->G);
   HIPCHK(hipGetLastError());
@@ -1421,6 +1518,7 @@ extern "C" int rg_safety_flags(rg_engine *e, uint32_t *out) {
 
 // Packs counters and safety summary of this engine's groups into redBuf (on the engine's stream).
 static int pack_summary(rg_engine *e) {
+  { int rs = settle_client(e); if (rs != RG_OK) return rs; }
   HIPCHK(hipMemsetAsync(e->redBuf, 0, (RG_N_COUNTERS + RG_N_SUMMARY) * sizeof(u64), e->stream));
   hipLaunchKernelGGL(k_summary, dim3((e->G + 255) / 256), dim3(256), 0, e->stream, e->S, e->G, e->P, e->PP,
                      (unsigned long long)e->G * (unsigned long long)e->now, (unsigned long long *)e->redBuf);
@@ -1536,7 +1634,7 @@ extern "C" int rg_device_buffers(rg_engine *e, void **counters_dev, void **flag_
   return RG_OK;
 }
 
-#if defined(RG_SECTION_COUNTS) || defined(RG_STAMPS)
+#if defined(RG_SECTION_COUNTS) || defined(RG_STAMPS) || defined(RG_DSTAMPS)
 // profiling builds only: how often each section of k_tick ran, per wave
 extern "C" int rg_debug_section_counts(rg_engine *e, uint64_t *out /* RG_CTR_SLOTS */) {
   LOCK(e);

@@ -16,6 +16,10 @@ struct DevPtrs {
   u64 *applyRec;                 // [G][L]
   int *startSeq, *partNext, *partEpoch, *recMax;   // [Gpad]
   int *schedPos, *schedRegs;     // [Gpad] scenario schedule: next op, the group's peer registers
+  // [Gpad] launches that only touch the groups that are due: wake = the group's next tick with something to do, as its
+  // last span left it (0: unknown, look again); settled = the tick up to which the group's lazy work (election-loop and
+  // monitor wake-up chains, client Starts) has been carried out
+  int *wake, *settled;
   unsigned *gflags;              // [Gpad]
   u64 *counters;                 // [RG_N_COUNTERS]
   unsigned *flagSummary;         // [2]
@@ -33,6 +37,8 @@ struct DevCfg {
   int acctBytes;
   int nbA, gwA, gwB;             // tick kernel: sets [0, nbA) hold gwA groups per wave, the others gwB
   int relaySets, relayChunk;     // relay launch: number of sets (0: plain launch) and ticks per chunk
+  int lazy;                      // some groups were skipped by earlier launches: a span starts from the group's `settled` tick
+  int dueWin;                    // due launch: groups per block window (<= 256)
 };
 
 // packed per-peer flag word
@@ -86,7 +92,7 @@ __device__ static inline void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ
 
 // per-wave counter block in LDS
 #define RG_CTR_SLOTS 56   // device counter block: RG_N_COUNTERS public counters, then profiling slots of the diagnostic builds
-#if defined(RG_SECTION_COUNTS) || defined(RG_STAMPS)
+#if defined(RG_SECTION_COUNTS) || defined(RG_STAMPS) || defined(RG_DSTAMPS)
 #define RG_WAVE_CTR_SLOTS RG_CTR_SLOTS
 #else
 #define RG_WAVE_CTR_SLOTS RG_N_COUNTERS   // a wave's LDS copy holds the public counters only
@@ -108,6 +114,13 @@ struct WaveCtr { unsigned c[RG_WAVE_CTR_SLOTS]; };
 #else
 #define STAMP(k) do { } while (0)
 #define STAMP_INIT do { } while (0)
+#endif
+#ifdef RG_DSTAMPS          // diagnostic builds only: shader cycles of the stretches of one span (set-up, first look, the passes, wind-up), slots 40..
+#define DSTAMP(k) do { unsigned long long _n = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&w->c[40 + (k)], (unsigned)(_n - _dstamp)); _dstamp = _n; } while (0)
+#define DSTAMP_INIT unsigned long long _dstamp = __builtin_readcyclecounter()
+#else
+#define DSTAMP(k) do { } while (0)
+#define DSTAMP_INIT do { } while (0)
 #endif
 
 enum { CD_SNAPTERM = 0, CD_SNAPVOTE, CD_SNAPLEN, CD_RNGCTR, CD_ROUNDSEQ, CD_AH_LO, CD_AH_HI, CD_APPLIED, CD_SNAPSYNC, CD_LASTTERM, CD_FIRSTOWN, CD_CTERM, CD_N };
@@ -229,6 +242,37 @@ __device__ static inline int next_random(LN &r, u64 key, int peer) {
   r.cd(CD_RNGCTR) = (int)(ctr + 1u);
   u64 h = stream_hash(key, STREAM_ELECTION, (unsigned)peer, ctr);
   return (int)((unsigned)(h >> 32) % (unsigned)RG_TIMEOUT_SPAN_MS) + RG_TIMEOUT_BASE_MS;
+}
+
+// first tick whose time is >= ms (ms >= 0)
+#define MS_TICK(ms) ((int)(((unsigned)((ms) > 0 ? (ms) : 0) + (unsigned)(RG_TICK_MS - 1)) / (unsigned)RG_TICK_MS))
+// scheduler slack of the election loop's 50 ms sleep: 0..3 ms, seeded
+__device__ static inline int sleep_slack(u64 key, int p, int now) {
+  unsigned h = (unsigned)key ^ ((unsigned)p * 0x9E3779B1u) ^ ((unsigned)now * 0x85EBCA6Bu);
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return (int)(h >> 30);
+}
+// Wake-ups of a peer that lie before tick T and change nothing but their own next wake-up time (raft.go:548-563 and 664-667
+// for a follower whose timer has not run out and for a leader; raft.go:421, 524 for a leader's poll behind a closed gate):
+// the tick kernel does not run them one by one but advances the two chains when the peer's group next has something to do,
+// and so does a host verb that changes whether or how the chains go on (crash, Kill) before it takes effect.
+template <class LN>
+__device__ static inline void catch_up_lane(LN &r, u64 key, int peer, int T) {
+  if (r.has(F_DEAD)) return;
+  const int st = r.state();
+  if (st != RG_CANDIDATE) {                                   // a candidate's wake-ups are rounds: never skipped
+    const int extra = st == RG_LEADER ? RG_ELECTION_LEADER_EXTRA_MS : 0;
+    int tau = MS_TICK(r.elNext);
+    while (tau < T) {
+      const int ms = tau * RG_TICK_MS;
+      r.elNext = ms + RG_ELECTION_PERIOD_MS + extra + sleep_slack(key, peer, ms);
+      tau = MS_TICK(r.elNext);
+    }
+  }
+  if (r.has(F_MONALIVE) && r.isLeader()) {                    // polls behind a closed gate: every second tick
+    const int tau = MS_TICK(r.monNext);
+    if (tau < T) r.monNext = (tau + ((T - 1 - tau) & ~1)) * RG_TICK_MS + RG_MONITOR_POLL_MS;
+  }
 }
 
 // Make() + readPersist() + the head of election(), raft.go:700-731,129-152,538-547.

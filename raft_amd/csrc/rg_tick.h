@@ -127,12 +127,6 @@ __device__ static inline int net_outcome(const NetRates &c, u64 key, bool reacha
   return 2 | NET_WIRE;
 }
 
-// scheduler slack of the election loop's 50 ms sleep: 0..3 ms, seeded
-__device__ static inline int sleep_slack(u64 key, int p, int now) {
-  unsigned h = (unsigned)key ^ ((unsigned)p * 0x9E3779B1u) ^ ((unsigned)now * 0x85EBCA6Bu);
-  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-  return (int)(h >> 30);
-}
 // first peer of a tick's actor order
 __device__ static inline int turn_start(u64 key, int tick, int P) {
   unsigned h = (unsigned)tick * 0x9E3779B1u + (unsigned)key;
@@ -152,19 +146,35 @@ __device__ static inline int turn_start(u64 key, int tick, int P) {
 // instantiation for engines without churn and with the first-leader Start mode (the benchmark's), with that code left out
 // (17 instead of 25 spilled registers).  w: the calling wave's counters of the launch.  stIn / stOut: the set's group words as the
 // previous span left them / for the next span, when spans of one launch run on different blocks (else null).
-template <int P, bool EXT, bool LEAN, bool COLS>
+//
+// DUE: the span of a due launch (k_tick_due).  `set` is then the first group of the calling WAVE's window, dueSlot the
+// lane's group as an offset from it and dueValid whether the lane has a group at all; waves of a block work through
+// different numbers of such spans, so nothing in here may wait for the block.
+template <int P, bool EXT, bool LEAN, bool COLS, bool DUE = false>
 __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, const DevCfg &c, const int set, const int t0, const int nticks, WaveCtr *w,
-                                          const int *stIn, int *stOut) {
+                                          const int *stIn, int *stOut, const int dueSlot = 0, const bool dueValid = false) {
   constexpr int PP = P <= 4 ? 4 : 8;        // stride of a group in the per-peer arrays and matrices in memory
   constexpr int NONE = 8;                   // "no such peer" for first-set-bit results
   constexpr int GPB = 4 * GrpN<P>::GWMAX;   // most groups of a 256-thread block
+  // Runs of log entries are handled by the whole wave for one lane at a time (one memory round trip per lane, whatever
+  // the run's length).  In a launch of a few ticks the LDS rings are cold and nearly every run is a single entry: there
+  // every lane handles its own short run (up to SHORTN entries), so the wave pays one round trip for all of them.
+#ifndef RG_SHORT_PATHS
+#define RG_SHORT_PATHS DUE
+#endif
+  constexpr bool SHORTP = RG_SHORT_PATHS;
+  constexpr int SHORTN = 4;
   // sets [0, nbA) hold gwA groups per wave, the rest gwB
-  const bool classA = set < c.nbA;
-  const int gw = classA ? c.gwA : c.gwB;
+  const bool classA = DUE || set < c.nbA;
+  const int gw = DUE ? GrpN<P>::GWMAX : (classA ? c.gwA : c.gwB);
   const GrpN<P> G(gw);
   const int wave = (int)(threadIdx.x >> 6);
+  DSTAMP_INIT;
+#ifdef RG_DSTAMPS
+  const unsigned long long _dstamp0 = _dstamp, _dreal0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
-  const int g0 = classA ? set * 4 * c.gwA : c.nbA * 4 * c.gwA + (set - c.nbA) * 4 * c.gwB;   // the set's first group: always < G
+  const int g0 = DUE ? set : (classA ? set * 4 * c.gwA : c.nbA * 4 * c.gwA + (set - c.nbA) * 4 * c.gwB);   // the set's first group: always < G
 #ifndef RG_RING
 #define RG_RING 4
 #endif
@@ -175,8 +185,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   // how busy a group is changes slowly: from the second span of a launch on, the set's groups are dealt to its
   // waves in the order of the rounds they sent in the span before (stIn word 6), busiest first, so that busy
   // groups share waves and the other waves finish early.  (Groups are independent: any dealing gives the same result.)
-  int slot = wave * gw + (G.lane / P);
-  if (stIn) {                                // the same for the whole block
+  int slot = DUE ? dueSlot : wave * gw + (G.lane / P);
+  if (!DUE && stIn) {                                // the same for the whole block
     int *const rate = &ringIdx[0][0], *const order = &ringIdx[RING / 2][0];   // scratch: the rings are not in use yet
     static_assert(GPB <= 256 * RING / 2, "scratch of the dealing");
     const int i = (int)threadIdx.x;
@@ -194,9 +204,11 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   }
   const int g = g0 + slot;
   const int peer = G.peer;
-  const bool valid = G.inWave && g < c.G;
+  const bool valid = DUE ? dueValid : (G.inWave && g < c.G);
   const int L = c.L;
   const unsigned gLoc = valid ? (unsigned)(g - g0) : 0u;       // in-range group for address arithmetic of idle lanes
+  // the group's slot in the block's per-group LDS words
+  const unsigned gSlot = DUE ? (unsigned)(wave * GrpN<P>::GWMAX + (G.inWave ? G.lane / P : 0)) : gLoc;
   const int gq = g0 + (int)gLoc;
   const long long gl = (long long)(G.inWave ? g : g0) * PP + (G.inWave ? peer : 0);   // slot in the per-peer arrays
   Rows lg, sn;
@@ -230,7 +242,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   const int tid = (int)threadIdx.x;
 #pragma unroll
   for (int q = 0; q < RING; q++) ringIdx[q][tid] = -1;
-  __syncthreads();
+  if constexpr (!DUE) __syncthreads();     // (lanes only ever read ring columns of their own wave)
 #define RING_PUSH(i_, tm_, cm_) do { const int _q = (i_) & (RING - 1); ringIdx[_q][tid] = (i_); ringTerm[_q][tid] = (tm_); ringCmd[_q][tid] = (cm_); } while (0)
   LaneT<lds_int *> r;
   r.cold = (lds_int *)&coldLds[0][threadIdx.x]; r.cs = 256;
@@ -240,6 +252,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   gStartSeq = stIn ? stIn[gLoc] : Sp->startSeq[gq]; gPartEpoch = stIn ? stIn[GPBPAD + gLoc] : Sp->partEpoch[gq];
 #define lVerified coldLds[CD_N + 5][threadIdx.x]
   lVerified = r.cd(CD_APPLIED);
+#ifdef RG_DSTAMPS
+  WAIT_LOADS();
+#endif
+  DSTAMP(1);
   if (stOut) {                               // rounds the group's peers have sent so far (see the end of the span)
     const int sent = G.gsum(valid ? r.cd(CD_ROUNDSEQ) : 0);
     if (valid && peer == 0) stOut[5 * GPBPAD + gLoc] = sent;
@@ -270,14 +286,16 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   // poll behind a closed gate) are not events: their chains are caught up when the group next runs a tick
   // (catch_up) and once more when the launch ends, so every word is as the tick-by-tick order leaves it.
   const int tEnd = t0 + nticks;
-#define MS_TICK(ms) ((int)(((unsigned)((ms) > 0 ? (ms) : 0) + (unsigned)(RG_TICK_MS - 1)) / (unsigned)RG_TICK_MS))    /* first tick whose time is >= ms (ms >= 0) */
 #define gNextStart coldLds[CD_N + 2][threadIdx.x]
-#define gChurnNext churnNext[gLoc]
+#define gChurnNext churnNext[gSlot]
   {
     int ns = 0x7fffffff;
     if (c.startPeriod > 0) {
+      // client Starts before tick tb have been carried out: tb is this span's first tick, or -- after launches that left
+      // the group alone -- the tick up to which its last span brought it
+      const int tb = (c.lazy && !stIn) ? Sp->settled[gq] : t0;
       ns = c.startFirst;
-      if (t0 > c.startFirst) ns += (t0 - c.startFirst + c.startPeriod - 1) / c.startPeriod * c.startPeriod;
+      if (tb > c.startFirst) ns += (tb - c.startFirst + c.startPeriod - 1) / c.startPeriod * c.startPeriod;
     }
     gNextStart = ns;
     // the group's next churn tick: the first positive multiple of the period in this span or after it (never skipped)
@@ -285,24 +303,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     if (valid) gChurnNext = (!LEAN && c.churnPeriod > 0) ? ((t0 > 1 ? t0 : 1) + c.churnPeriod - 1) / c.churnPeriod * c.churnPeriod : 0x7fffffff;
   }
   // wake-ups of this lane that lie before tick T and change nothing else
-  auto catch_up = [&](int T) {
-    if (valid && !r.has(F_DEAD)) {
-      const int st = r.state();
-      if (st != RG_CANDIDATE) {                                   // a candidate's wake-ups are rounds: never skipped
-        const int extra = st == RG_LEADER ? RG_ELECTION_LEADER_EXTRA_MS : 0;
-        int tau = MS_TICK(r.elNext);
-        while (tau < T) {
-          const int ms = tau * RG_TICK_MS;
-          r.elNext = ms + RG_ELECTION_PERIOD_MS + extra + sleep_slack(key, peerL, ms);
-          tau = MS_TICK(r.elNext);
-        }
-      }
-      if (r.has(F_MONALIVE) && r.isLeader()) {                    // polls behind a closed gate: every second tick
-        const int tau = MS_TICK(r.monNext);
-        if (tau < T) r.monNext = (tau + ((T - 1 - tau) & ~1)) * RG_TICK_MS + RG_MONITOR_POLL_MS;
-      }
-    }
-  };
+  auto catch_up = [&](int T) { if (valid) catch_up_lane(r, key, peerL, T); };
   // first tick >= from at which the lane's group has something to do
   auto next_event = [&](int from) -> int {
     int cand = 0x7fffffff;       // this lane's next event
@@ -376,7 +377,31 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
       SECTION_COUNT(w, 12);
       SYNC_STORES();
       const int nOwn = r.cd(CD_APPLIED) - lVerified;
-      do {
+      if constexpr (SHORTP) {
+        const bool mine = need && nOwn <= SHORTN;
+        if (mine) {
+          u64 cmd[SHORTN], seen[SHORTN];
+#pragma unroll
+          for (int j = 0; j < SHORTN; j++) {           // all loads first (past the run's end: its last entry again)
+            const int i = lVerified + 1 + (j < nOwn ? j : nOwn - 1), ic = i < L ? i : L - 1;
+            cmd[j] = *lg.cmdp(ic, peer); seen[j] = rec(ic);
+          }
+          bool differs = false;
+          unsigned accLo = 0, accHi = 0;
+#pragma unroll
+          for (int j = 0; j < SHORTN; j++) {
+            if (j < nOwn) {
+              differs |= cmd[j] != seen[j];
+              const u64 wd = apply_word(cmd[j], lVerified + 1 + j);
+              accLo += (unsigned)wd; accHi += (unsigned)(wd >> 32);
+            }
+          }
+          coldLds[CD_AH_LO][tid] += (int)accLo; coldLds[CD_AH_HI][tid] += (int)accHi;
+          if (differs) gfl |= RG_FLAG_STATE_MACHINE;
+        }
+        vm &= ~__builtin_amdgcn_ballot_w64(mine);
+      }
+      while (vm) {
         const int src = (int)__builtin_ctzll(vm);
         vm &= vm - 1;
         const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), rOffB = (unsigned)__builtin_amdgcn_readlane((int)rOff, src);
@@ -398,7 +423,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           atomicAdd((unsigned *)&coldLds[CD_AH_HI][tTid], accHi);
         }
         if (wave_any(differs) && G.lane == src) gfl |= RG_FLAG_STATE_MACHINE;
-      } while (vm);
+      }
       if (need) lVerified = r.cd(CD_APPLIED);
     }
   };
@@ -489,8 +514,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     }
   };
 
+  DSTAMP(2);
   int tg = next_event(t0);
   if (!valid) tg = 0x7fffffff;
+  DSTAMP(3);
   while (wave_any(tg < tEnd)) {
     const bool run = tg < tEnd;            // the lane's group runs its tick tg in this pass
     SECTION_COUNT(w, 14);
@@ -909,6 +936,19 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
             if (hm) SECTION_COUNT(w, 10);
             if (wave_any(scan)) SECTION_COUNT(w, 11);
             if (hm || wave_any(scan)) SYNC_STORES();
+            if constexpr (SHORTP) {
+              const bool mine = viaHbm && k <= SHORTN;
+              if (mine) {
+                int tm[SHORTN]; u64 cm[SHORTN];
+#pragma unroll
+                for (int j = 0; j < SHORTN; j++) { const int i = nx + (j < k ? j : k - 1); tm[j] = *lg.termp(i, sIdx); cm[j] = *lg.cmdp(i, sIdx); }
+#pragma unroll
+                for (int j = 0; j < SHORTN; j++) {
+                  if (j < k) { const int i = nx + j; *lg.termp(i, peer) = tm[j]; *lg.cmdp(i, peer) = cm[j]; RING_PUSH(i, tm[j], cm[j]); }
+                }
+              }
+              hm &= ~__builtin_amdgcn_ballot_w64(mine);
+            }
             while (hm) {
               const int src = (int)__builtin_ctzll(hm);
               hm &= hm - 1;
@@ -1074,6 +1114,20 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
             if (want <= r.commit && nRec > 0 && ringIdx[q][tid] != want) slow = true;
           }
           u64 sm = __builtin_amdgcn_ballot_w64(slow);
+          if constexpr (SHORTP) {
+            const bool mine = slow && nRec <= SHORTN;
+            if (wave_any(mine)) {
+              SYNC_STORES();
+              if (mine) {
+                u64 cmd[SHORTN];
+#pragma unroll
+                for (int j = 0; j < SHORTN; j++) { const int i = recLo + 1 + (j < nRec ? j : nRec - 1); cmd[j] = *lg.cmdp(i < L ? i : L - 1, peer); }
+#pragma unroll
+                for (int j = 0; j < SHORTN; j++) { if (j < nRec) { const int i = recLo + 1 + j; rec(i < L ? i : L - 1) = cmd[j]; } }
+              }
+              sm &= ~__builtin_amdgcn_ballot_w64(mine);
+            }
+          }
           if (nRec > 0 && !slow) {
             for (int j = 0; j < nRec; j++) {
               const int i = recLo + 1 + j, q = i & (RING - 1);
@@ -1161,9 +1215,13 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     }
     STAMP(11);
   }
+  DSTAMP(4);
   client_starts(valid, tEnd - 1);          // Starts and wake-ups the groups skipped towards the end of the launch
+  DSTAMP(5);
   catch_up(tEnd);
+  DSTAMP(6);
   verify_applied(valid);
+  DSTAMP(7);
 
 #undef SYNC_STORES
 #undef RING_PUSH
@@ -1185,13 +1243,12 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 #undef gRecMax
 #undef gNextStart
 #undef gChurnNext
-#undef MS_TICK
 #undef gPartEpoch
 #undef nextRow
 #undef matchRow
 #undef rec
 #undef rOff
-  if (G.inWave) r.store(*Sp, gl);
+  if (DUE ? valid : G.inWave) r.store(*Sp, gl);
   gfl = G.gor(gfl);
   if (stOut) {                               // rounds sent in this span: how busy the group is, for the next span's dealing
     const int sent = G.gsum(valid ? r.cd(CD_ROUNDSEQ) : 0);
@@ -1202,6 +1259,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   }
   if (valid && peer == 0) {
     Sp->startSeq[g] = startSeqOut; Sp->partNext[g] = partNextOut; Sp->partEpoch[g] = partEpochOut; Sp->recMax[g] = recMaxOut;
+    Sp->wake[g] = tg; Sp->settled[g] = tEnd;   // the group's next tick with something to do (>= tEnd); all lazy work done up to tEnd
     if (stOut) {
       const unsigned all = (stIn ? (unsigned)stIn[4 * GPBPAD + gLoc] : Sp->gflags[g]) | gfl;
       stOut[gLoc] = startSeqOut; stOut[GPBPAD + gLoc] = partEpochOut; stOut[2 * GPBPAD + gLoc] = partNextOut; stOut[3 * GPBPAD + gLoc] = recMaxOut;
@@ -1209,6 +1267,19 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
       if (gfl) Sp->gflags[g] = all;
     } else if (gfl) Sp->gflags[g] |= gfl;
   }
+  DSTAMP(8);
+#ifdef RG_DSTAMPS
+  {
+    const unsigned ng = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(valid && peer == 0));
+    const unsigned tot = (unsigned)(__builtin_readcyclecounter() - _dstamp0);
+    if (G.lane == 0) {
+      atomicAdd(&w->c[40 + 9], 1u); atomicAdd(&w->c[40 + 10], ng); atomicAdd(&w->c[40 + 15], (unsigned)(__builtin_amdgcn_s_memrealtime() - _dreal0));
+      if (tot > 60000u) atomicAdd(&w->c[40 + 12], 1u);
+      if (tot > 120000u) atomicAdd(&w->c[40 + 13], 1u);
+      if (tot > 200000u) atomicAdd(&w->c[40 + 14], 1u);
+    }
+  }
+#endif
 }
 
 // The tick kernel.  Plain launch (c.relaySets == 0): block b runs set b through all nticks.
@@ -1277,6 +1348,50 @@ __device__ __forceinline__ void tick_launch(const DevPtrs *Sp, HotPtrs &H, DevCf
   if (lane < RG_WAVE_CTR_SLOTS && w->c[lane]) atomicAdd((unsigned long long *)&Sp->counters[lane], (unsigned long long)w->c[lane]);
 }
 
+// Due launch: a launch of few ticks in which most groups have nothing to do (on the benchmark workload a group has an
+// event in one tick of six).  Every span leaves the group's next event tick in `wake`; a block of this kernel looks at the
+// wake words of its window of c.dueWin (<= 256) consecutive groups, one coalesced read, and runs the span for those that
+// fall inside [t0, t0 + nticks) only, shared out evenly among its four waves, 64/P to a wave at most; the others are not
+// touched at all -- their lazy work (wake-up chains, client Starts) waits until they next run, exactly as it does inside
+// a long launch.  A span of a few ticks is bound by the instructions of its set-up, its one or two passes and its
+// wind-up, which cost a wave the same whether it holds one group or twelve: hence few, full waves, about one per SIMD.
+// The window's groups are at most 256 apart, so the uniform base + 32-bit lane offset addressing of tick_span holds.
+template <int P, bool EXT, bool COLS>
+__device__ __forceinline__ void due_launch(const DevPtrs *Sp, const HotPtrs &H, const DevCfg &c, int t0, int nticks) {
+  constexpr int GWMAX = GrpN<P>::GWMAX;
+  __shared__ WaveCtr dctr[4];
+  __shared__ int pick[256];
+  __shared__ int waveDue[4];
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  WaveCtr *w = &dctr[wave];
+  if (lane < RG_WAVE_CTR_SLOTS) w->c[lane] = 0;
+  const long long first = (long long)blockIdx.x * c.dueWin;        // the window's first group
+  const int tEnd = t0 + nticks;
+  const int i = (int)threadIdx.x;
+  int wk = 0x7fffffff;
+  if (i < c.dueWin && first + i < c.G) wk = Sp->wake[first + i];
+  const u64 m = __builtin_amdgcn_ballot_w64(wk < tEnd);
+  if (lane == 0) waveDue[wave] = (int)__builtin_popcountll(m);
+  __syncthreads();
+  int before = 0, nDue = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) { const int n = waveDue[q]; before += q < wave ? n : 0; nDue += n; }
+  if ((m >> lane) & 1ull) pick[before + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;   // the k-th due group of the window
+  __syncthreads();
+  for (int b0 = 0; b0 < nDue; b0 += 4 * GWMAX) {
+    const int nb = nDue - b0 < 4 * GWMAX ? nDue - b0 : 4 * GWMAX;  // groups of this round, shared out evenly
+    const int per = (nb + 3) >> 2;
+    const int lo = b0 + wave * per, hi = b0 + ((wave + 1) * per < nb ? (wave + 1) * per : nb);
+    if (lo >= hi) continue;                                        // nothing left for this wave (the same for all its lanes)
+    const int k = lo + lane / P;
+    const bool v = lane / P < GWMAX && k < hi;
+    const int off = pick[v ? k : lo];                              // lanes without a group look at the wave's first one and store nothing
+    tick_span<P, EXT, false, COLS, true>(Sp, H, c, (int)first, t0, nticks, w, nullptr, nullptr, off, v);
+  }
+  __syncthreads();
+  if (lane < RG_WAVE_CTR_SLOTS && w->c[lane]) atomicAdd((unsigned long long *)&Sp->counters[lane], (unsigned long long)w->c[lane]);
+}
+
 // (the extended instantiation carries the schedule's and the apply ring's code and is not asked to fit 4 waves per SIMD)
 #ifdef RG_SPEC_P
 extern "C" __global__ __launch_bounds__(256, RG_SPEC_EXT ? 2 : RG_TICK_WAVES) void k_tick_spec(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
@@ -1286,6 +1401,10 @@ extern "C" __global__ __launch_bounds__(256, RG_SPEC_EXT ? 2 : RG_TICK_WAVES) vo
 template <int P, bool EXT, bool LEAN, bool COLS>
 __global__ __launch_bounds__(256, EXT ? 2 : RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
   tick_launch<P, EXT, LEAN, COLS>(Sp, H, c, t0, nticks);
+}
+template <int P, bool EXT, bool COLS>
+__global__ __launch_bounds__(256, EXT ? 2 : RG_TICK_WAVES) void k_tick_due(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
+  due_launch<P, EXT, COLS>(Sp, H, c, t0, nticks);
 }
 #endif
 

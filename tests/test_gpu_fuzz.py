@@ -128,13 +128,19 @@ def _run(seed, tweak=None, until=1500):
     t = 0
     rk = random.Random(777 + seed)
     step = e.step_noalloc if random.Random(99 + seed).random() < 0.15 else e.step   # (its own stream) some cases through the entry point that allocates nothing
+    # (its own stream) how often the state is read back: launches of a few ticks leave the groups without an event alone, and a
+    # read brings them up to date; with rarer reads they stay behind across several launches and the host verbs in between
+    check_every = random.Random(555 + seed).choice([1, 1, 3, 10])
+    i_step = 0
     while t < until:
         n = rng.choice([1, 1, 2, 3, 5, 8, 13, 50, 200, 600])
         o.step(n)
         step(n)
         t += n
-        d = diff_states(o, e)
-        assert not d, "config %r after tick %d: %s" % (kw, t, "; ".join(d[:5]))
+        i_step += 1
+        if i_step % check_every == 0 or t >= until:
+            d = diff_states(o, e)
+            assert not d, "config %r after tick %d: %s" % (kw, t, "; ".join(d[:5]))
         if rk.random() < 0.04:                      # rf.Kill() from the host
             g, p = rk.randrange(kw["n_groups"]), rk.randrange(kw["n_peers"])
             o.kill(g, p)

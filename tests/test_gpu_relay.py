@@ -32,6 +32,7 @@ def test_relay_matches_oracle(monkeypatch, capfd, kw, groups, slot_waves, chunks
     monkeypatch.setenv("RAFTGPU_SLOT_WAVES", str(slot_waves))
     monkeypatch.setenv("RAFTGPU_RELAY_CHUNKS", str(chunks))
     monkeypatch.setenv("RAFTGPU_TRACE_LAUNCH", "1")
+    monkeypatch.setenv("RAFTGPU_DUE_MAX_TICKS", "0")       # the short launches too go through the relay here, not through due launches
     cfg = dict(kw, n_groups=groups)
     o, e = OracleEngine(_abi.make_config(**cfg)), Engine(_abi.make_config(**cfg))
     for n in launches:
