@@ -1045,7 +1045,8 @@ extern "C" int rg_reset_groups(rg_engine *e, const int32_t *groups, int64_t n) {
   if (n == 0) return RG_OK;
   for (int64_t i = 0; i < n; i++) if (groups[i] < 0 || groups[i] >= e->G) return RG_ERR_RANGE;
   { std::vector<int> level; if (batch_levels(e, groups, 1, (size_t)n, level) > 0) return RG_ERR_ARG; }   // one block per group: no repeats
-  int rc = run_derive(e);
+  int rc = settle_client(e);             // client Starts the old peers still owe are carried out (and counted) first
+  if (rc == RG_OK) rc = run_derive(e);
   if (rc != RG_OK) return rc;
   TmpBuf tb;
   int *dg = tb.get<int>((size_t)n);
