@@ -215,7 +215,14 @@ int rg_set_stream(rg_engine *e, void *hip_stream);
 /* Advance every group n_ticks ticks (election timers raft.go:536-669, leader
  * loop :387-530, handlers :200-321, apply :672-688, persist :107-123) in ONE
  * kernel launch; state stays resident in HBM between calls.  Asynchronous on
- * the engine's stream; rg_sync waits. */
+ * the engine's stream; rg_sync waits.
+ * A call of at most 4 ticks (the tester's way of driving an instance: one tick at a time, verbs in between) only runs
+ * the groups that have something to do inside those ticks -- every group's next such tick is kept next to its state
+ * -- and leaves the others alone: groups whose peers are all crashed (slots waiting for a config) cost 4 bytes of
+ * reading each.  What the untouched groups would have done meanwhile changes nothing but their own wake-up times (and,
+ * with a device client, appends the client's Starts); it is carried out when the group next runs or before the host
+ * reads state, so every call returns what tick-by-tick execution returns.  RAFTGPU_DUE_MAX_TICKS in the environment
+ * changes the limit (0: every call runs every group). */
 int rg_step(rg_engine *e, int32_t n_ticks);
 /* rg_step without any allocation.  No counterpart in the reference: it is for callers that cannot allocate
  * device or host memory while they step -- code under HIP graph capture, tight serving loops, harnesses that

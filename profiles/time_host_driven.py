@@ -18,13 +18,22 @@ rounds = 100
 e.sync()
 t0 = time.perf_counter()
 accepted = 0
+parts = [0.0, 0.0, 0.0, 0.0]              # filling the requests, rg_start_batch, counting the answers, rg_step
 for i in range(rounds):
+    ta = time.perf_counter()
     reqs["command"] = (np.arange(G, dtype=np.uint64) << np.uint64(20)) + np.uint64(i + 1)
+    tb = time.perf_counter()
     e._check(e._lib.rg_start_batch(e._h, ptr, G), "start_batch")   # what Engine.start_batch_arrays does, without its copies
+    tc = time.perf_counter()
     accepted += int(np.count_nonzero(reqs["is_leader"]))
+    td = time.perf_counter()
     e.step(5)
+    te = time.perf_counter()
+    for k, v in enumerate((tb - ta, tc - tb, td - tc, te - td)):
+        parts[k] += v
 e.sync()
 dt = time.perf_counter() - t0
+print("per round: fill %.0f us, rg_start_batch %.0f us, count %.0f us, rg_step (asynchronous) %.0f us" % tuple(x / rounds * 1e6 for x in parts))
 c = e.counters()
 print("%d groups: %d rounds of (Start on every group + 5 ticks) in %.3f s: %.3e Starts/s (%d accepted), %.3e group-ticks/s, %d entries committed, flags %s" % (
     G, rounds, dt, G * rounds / dt, accepted, G * 5 * rounds / dt, c["entries_committed"], e.safety_flags()))
