@@ -163,7 +163,10 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 #define RG_SHORT_PATHS DUE
 #endif
   constexpr bool SHORTP = RG_SHORT_PATHS;
-  constexpr int SHORTN = 4;
+#ifndef RG_SHORTN
+#define RG_SHORTN 4
+#endif
+  constexpr int SHORTN = RG_SHORTN;
   // sets [0, nbA) hold gwA groups per wave, the rest gwB
   const bool classA = DUE || set < c.nbA;
   const int gw = DUE ? GrpN<P>::GWMAX : (classA ? c.gwA : c.gwB);
@@ -537,11 +540,17 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     // ------------------------------------------------------------ 1. control
     const bool partNow = c.partPeriod > 0 && run && t == gPartNext;
     const bool churnNow = (!LEAN && c.churnPeriod > 0) && run && t == gChurnNext;
-    // a Start of a tick the group skipped precedes this tick's control events (otherwise one call below does both)
-    // (groups without a control event in this tick run theirs up to this tick at the same time)
+    // a Start of a tick the group skipped precedes this tick's churn and schedule events, which change who would take it
+    // (otherwise one call below does both; groups without such an event in this tick run theirs up to this tick at the
+    // same time).  A reshuffle of the partition sides changes nothing a Start looks at -- who leads, who is connected to
+    // the tester -- and needs no such call.
     bool schedNow = false;
     if constexpr (EXT) schedNow = H.schedN > 0 && run && valid && gSchedPos < H.schedN && H.sched[gSchedPos].tick <= t;
+#ifdef RG_EARLY_STARTS_PART
     if ((c.partPeriod > 0 || (!LEAN && c.churnPeriod > 0) || EXT) && wave_any(partNow || churnNow || schedNow)) client_starts(run, (partNow || churnNow || schedNow) ? t - 1 : t);
+#else
+    if (((!LEAN && c.churnPeriod > 0) || EXT) && wave_any(churnNow || schedNow)) client_starts(run, (churnNow || schedNow) ? t - 1 : t);
+#endif
     STAMP(12);
     if constexpr (EXT) {
       // ---- 0. the scenario schedule: the tester's verbs, by every group on its own peers (config.go:99-278, 302-332, 430-477)

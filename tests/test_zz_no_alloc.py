@@ -54,6 +54,7 @@ def test_noalloc_allocates_nothing():
         big.step_noalloc(2500)       # relay launch
         small.step_noalloc(400)      # plain launch
         big.step_noalloc(7)          # plain launch of a large engine
+        big.step_noalloc(2)          # due launch: only the groups with an event inside it
     big.sync()
     small.sync()
     assert _free_bytes() == free0
