@@ -18,6 +18,8 @@ def run(label, env):
         os.environ.pop(k, None)
     os.environ.update(env)
     e = Engine(_abi.make_config(**kw))
+    if os.environ.get("SPEC"):
+        e.specialize()                   # the kernels compiled for this configuration
     out = []
     for n in ns:
         e.reset(); e.step(3000); e.sync()

@@ -117,7 +117,7 @@ struct rg_engine {
   std::vector<unsigned> cmdStamp; std::vector<int> cmdSeen; unsigned cmdEpoch;   // per group: batch that last named it, and how often so far
   // the tick kernel compiled for this engine's configuration (rg_specialize), and what it was compiled for
   bool specWanted;
-  hipModule_t specMod; hipFunction_t specFn;
+  hipModule_t specMod; hipFunction_t specFn, specDueFn;
   bool specExt, specLean; DevCfg specFor;
   // the cross-GPU exchange: counters + safety summary packed in one device buffer, reduced in place
   u64 *redBuf;                    // device: [RG_N_COUNTERS + RG_N_SUMMARY]
@@ -234,6 +234,8 @@ static void fill_devcfg(rg_engine *e) {
     if (const char *ov = getenv("RAFTGPU_DUE_WIN")) win = atoi(ov);           // tuning aid
     e->dueWin = (int)(win < 1 ? 1 : (win > 256 ? 256 : win));
     d.dueWin = e->dueWin;
+    d.dueSplit = 2;                     // two blocks per window: the second runs the rounds beyond the first at the same time
+    if (const char *ov = getenv("RAFTGPU_DUE_SPLIT")) { const int v = atoi(ov); if (v >= 1 && v <= 8) d.dueSplit = v; }   // tuning aid
     e->dueMaxTicks = RG_DUE_MAX_TICKS;
     if (const char *ov = getenv("RAFTGPU_DUE_MAX_TICKS")) e->dueMaxTicks = atoi(ov);   // tuning / test aid; 0: every launch is a full one
     // (the lane offsets of a window must fit 32 bits)
@@ -353,8 +355,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   if (rc == RG_OK) rc = dalloc(e, &S.schedPos, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.schedRegs, (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.gflags, (size_t)e->Gpad);
-  if (rc == RG_OK) rc = dalloc(e, &S.wake, (size_t)e->Gpad);
-  if (rc == RG_OK) rc = dalloc(e, &S.settled, (size_t)e->Gpad);
+  if (rc == RG_OK) rc = dalloc(e, &S.wakeSettled, 2 * (size_t)e->Gpad);
   if (rc == RG_OK) rc = dalloc(e, &S.counters, (size_t)RG_CTR_SLOTS);
   if (rc == RG_OK) rc = dalloc(e, &S.flagSummary, (size_t)2);
   if (rc == RG_OK) rc = dalloc(e, &e->redBuf, (size_t)(RG_N_COUNTERS + RG_N_SUMMARY));
@@ -596,7 +597,7 @@ static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
   if (e->specMod) {                                          // launches of the old kernel may still be running
     HIPCHK(hipStreamSynchronize(e->stream));
     hipModuleUnload(e->specMod);
-    e->specMod = nullptr; e->specFn = nullptr;
+    e->specMod = nullptr; e->specFn = nullptr; e->specDueFn = nullptr;
   }
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, e->cfg.device));
@@ -629,7 +630,8 @@ static int build_spec(rg_engine *e, bool ext, bool lean, const DevCfg &c) {
   int rc = compile_spec(r, opts, code);
   if (rc != RG_OK) return rc;
   HIPCHK(hipModuleLoadData(&e->specMod, code.data()));
-  if (hipModuleGetFunction(&e->specFn, e->specMod, "k_tick_spec") != hipSuccess) { hipModuleUnload(e->specMod); e->specMod = nullptr; e->specFn = nullptr; return RG_ERR_HIP; }
+  if (hipModuleGetFunction(&e->specFn, e->specMod, "k_tick_spec") != hipSuccess ||
+      hipModuleGetFunction(&e->specDueFn, e->specMod, "k_tick_spec_due") != hipSuccess) { hipModuleUnload(e->specMod); e->specMod = nullptr; e->specFn = nullptr; e->specDueFn = nullptr; return RG_ERR_HIP; }
   e->specExt = ext; e->specLean = lean; e->specFor = c;
   return RG_OK;
 }
@@ -645,10 +647,20 @@ static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage,
   const DevPtrs *dS = e->dS;
   if (!forceFull && !e->wakeDirty && n_ticks > 0 && n_ticks <= e->dueMaxTicks) {
     // a due launch: the groups with an event inside the launch, found from their wake words by the kernel itself
-    const unsigned dblocks = (unsigned)(((long long)e->G + e->dueWin - 1) / e->dueWin);
+    const unsigned dblocks = (unsigned)(((long long)e->G + e->dueWin - 1) / e->dueWin) * (unsigned)dc.dueSplit;
     dc.lazy = e->lazy ? 1 : 0;
     const bool extD = dc.acctBytes || H.applyCap > 0 || H.netCfg || H.schedN > 0;
     if (getenv("RAFTGPU_TRACE_LAUNCH")) fprintf(stderr, "raftgpu: k_tick_due ticks=%d blocks=%u window=%d lazy=%d\n", n_ticks, dblocks, e->dueWin, dc.lazy);
+    if (e->specWanted) {                 // the kernel compiled for this configuration, if there is one that fits (never compiled here)
+      const bool leanD = dc.churnPeriod == 0 && dc.startMode == RG_START_ONE && !extD;
+      if (e->specDueFn && e->specExt == extD && e->specLean == leanD && spec_same(e->specFor, dc)) {
+        int t0 = (int)e->now, n = n_ticks;
+        void *params[] = {(void *)&dS, (void *)&H, (void *)&dc, (void *)&t0, (void *)&n};
+        HIPCHK(hipModuleLaunchKernel(e->specDueFn, dblocks, 1, 1, 256, 1, 1, 0, e->stream, params, nullptr));
+        e->lazy = true;
+        return RG_OK;
+      }
+    }
 #define DUE_LAUNCH2(PEERS, COLS) do { \
     if (extD) hipLaunchKernelGGL((k_tick_due<PEERS, true, COLS>), dim3(dblocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
     else hipLaunchKernelGGL((k_tick_due<PEERS, false, COLS>), dim3(dblocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)

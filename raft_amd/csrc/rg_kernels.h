@@ -41,7 +41,7 @@ __global__ void k_host_cmds(DevPtrs S, DevCfg c, int PP, HostCmd *cmds, int n, i
     case OP_GETSTATE: cm.r1 = r.term; cm.r2 = r.isLeader() ? 1 : 0; break;
     }
     r.store(S, gl);
-    if (cm.op != OP_GETSTATE) S.wake[g] = 0;          // the group's next event has to be worked out again
+    if (cm.op != OP_GETSTATE) RG_WAKE(S, g) = 0;          // the group's next event has to be worked out again
     if (gfl) atomicOr(&S.gflags[g], gfl);
     cmds[i] = cm;
   }
@@ -69,7 +69,7 @@ __global__ void k_rpc_vote(DevPtrs S, DevCfg c, int PP, const int *groups, const
       commit_vote(r, d, a.term, a.candidate, now, lg, sn, p, c.L, &sctr);
       replies[i].term = d.rTerm; replies[i].granted = d.grant ? 1 : 0;
       r.store(S, gl);
-      S.wake[g] = 0;
+      RG_WAKE(S, g) = 0;
     }
   }
   __syncthreads();
@@ -121,7 +121,7 @@ __global__ void k_rpc_append(DevPtrs S, DevCfg c, int PP, const int *groups, con
       }
       replies[i] = rep;
       r.store(S, gl);
-      S.wake[g] = 0;
+      RG_WAKE(S, g) = 0;
       if (gfl) atomicOr(&S.gflags[g], gfl);
     }
   }
@@ -151,7 +151,7 @@ __device__ static inline void init_lane(const DevPtrs &S, const DevCfg &c, int P
   for (int q = 0; q < PP; q++) { S.nextIdx[gl * PP + q] = 0; S.matchIdx[gl * PP + q] = 0; }
   if (p == 0) {
     S.startSeq[g] = 0; S.partEpoch[g] = 0; S.recMax[g] = 0; S.gflags[g] = 0;
-    S.wake[g] = 0; S.settled[g] = nowTick;
+    RG_WAKE(S, g) = 0; RG_SETTLED(S, g) = nowTick;
     S.schedRegs[g] = 0xFFFF;                                   // four empty registers; the schedule's position is the engine's
     S.partNext[g] = g < c.G && c.partPeriod > 0 ? nowTick + c.partPeriod : 0;
   }

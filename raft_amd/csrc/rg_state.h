@@ -16,10 +16,15 @@ struct DevPtrs {
   u64 *applyRec;                 // [G][L]
   int *startSeq, *partNext, *partEpoch, *recMax;   // [Gpad]
   int *schedPos, *schedRegs;     // [Gpad] scenario schedule: next op, the group's peer registers
-  // [Gpad] launches that only touch the groups that are due: wake = the group's next tick with something to do, as its
-  // last span left it (0: unknown, look again); settled = the tick up to which the group's lazy work (election-loop and
-  // monitor wake-up chains, client Starts) has been carried out
-  int *wake, *settled;
+  // [Gpad][2] launches that only touch the groups that are due: word 0, wake = the group's next tick with something to do, as
+  // its last span left it (0: unknown, look again); word 1, settled = the tick up to which the group's lazy work
+  // (election-loop and monitor wake-up chains, client Starts) has been carried out.  One 8-byte pair per group, written by
+  // one store at the end of a span: blocks of a due launch that share a window must agree on which of its groups were due
+  // when the launch began, and a pair shows that either way -- wake below the launch's end (not run yet) or settled equal
+  // to it (run by this very launch).
+  int *wakeSettled;
+#define RG_WAKE(S, g) (S).wakeSettled[2 * (size_t)(g)]
+#define RG_SETTLED(S, g) (S).wakeSettled[2 * (size_t)(g) + 1]
   unsigned *gflags;              // [Gpad]
   u64 *counters;                 // [RG_N_COUNTERS]
   unsigned *flagSummary;         // [2]
@@ -38,7 +43,7 @@ struct DevCfg {
   int nbA, gwA, gwB;             // tick kernel: sets [0, nbA) hold gwA groups per wave, the others gwB
   int relaySets, relayChunk;     // relay launch: number of sets (0: plain launch) and ticks per chunk
   int lazy;                      // some groups were skipped by earlier launches: a span starts from the group's `settled` tick
-  int dueWin;                    // due launch: groups per block window (<= 256)
+  int dueWin, dueSplit;          // due launch: groups per block window (<= 256); blocks that share a window's rounds
 };
 
 // packed per-peer flag word

@@ -296,7 +296,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     if (c.startPeriod > 0) {
       // client Starts before tick tb have been carried out: tb is this span's first tick, or -- after launches that left
       // the group alone -- the tick up to which its last span brought it
-      const int tb = (c.lazy && !stIn) ? Sp->settled[gq] : t0;
+      const int tb = (c.lazy && !stIn) ? RG_SETTLED(*Sp, gq) : t0;
       ns = c.startFirst;
       if (tb > c.startFirst) ns += (tb - c.startFirst + c.startPeriod - 1) / c.startPeriod * c.startPeriod;
     }
@@ -518,7 +518,14 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   };
 
   DSTAMP(2);
-  int tg = next_event(t0);
+  int tg;
+  if constexpr (DUE) {
+    // The wake word is the tick the group's last span was going to run next, so the launches continue exactly as one long
+    // launch would have; only a group the host has touched since (wake 0) has to look again.
+    const int wk = valid ? RG_WAKE(*Sp, gq) : 1;
+    tg = wk > t0 ? wk : t0;
+    if (wave_any(wk == 0)) { const int ne = next_event(t0); if (wk == 0) tg = ne; }
+  } else tg = next_event(t0);
   if (!valid) tg = 0x7fffffff;
   DSTAMP(3);
   while (wave_any(tg < tEnd)) {
@@ -1268,7 +1275,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   }
   if (valid && peer == 0) {
     Sp->startSeq[g] = startSeqOut; Sp->partNext[g] = partNextOut; Sp->partEpoch[g] = partEpochOut; Sp->recMax[g] = recMaxOut;
-    Sp->wake[g] = tg; Sp->settled[g] = tEnd;   // the group's next tick with something to do (>= tEnd); all lazy work done up to tEnd
+    // the group's next tick with something to do (>= tEnd), and: all lazy work done up to tEnd -- one store for the pair
+    *(u64 *)&RG_WAKE(*Sp, g) = ((u64)(unsigned)tEnd << 32) | (u64)(unsigned)tg;
     if (stOut) {
       const unsigned all = (stIn ? (unsigned)stIn[4 * GPBPAD + gLoc] : Sp->gflags[g]) | gfl;
       stOut[gLoc] = startSeqOut; stOut[GPBPAD + gLoc] = partEpochOut; stOut[2 * GPBPAD + gLoc] = partNextOut; stOut[3 * GPBPAD + gLoc] = recMaxOut;
@@ -1305,17 +1313,22 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 // of its own to write back is not known to be refetched for its other bytes: the per-group words travel through
 // a staging area with whole lines per set instead (the host lays out relay launches so that no other array has
 // a line with two sets in it).
-template <int P, bool EXT, bool LEAN, bool COLS>
-__device__ __forceinline__ void tick_launch(const DevPtrs *Sp, HotPtrs &H, DevCfg &c, int t0, int nticks) {
 #ifdef RG_SPEC_P
-  // A build for one engine's configuration (rg_specialize compiles this file at run time): what rg_create fixed is a
-  // compile-time constant here, so it costs no scalar register and folds into the arithmetic around it.
+// A build for one engine's configuration (rg_specialize compiles this file at run time): what rg_create fixed is a
+// compile-time constant here, so it costs no scalar register and folds into the arithmetic around it.
+__device__ __forceinline__ void spec_constants(DevCfg &c) {
   c.P = RG_SPEC_P; c.L = RG_SPEC_L; c.rowBytes = RG_SPEC_ROWBYTES; c.cmdOff = RG_SPEC_CMDOFF; c.cols = RG_SPEC_COLS; c.groupBytes = RG_SPEC_GROUPBYTES;
   c.reqDrop = RG_SPEC_REQDROP; c.replyDrop = RG_SPEC_REPLYDROP; c.replyDelay = RG_SPEC_REPLYDELAY;
   c.startPeriod = RG_SPEC_STARTPERIOD; c.startFirst = RG_SPEC_STARTFIRST; c.startMax = RG_SPEC_STARTMAX; c.startMode = RG_SPEC_STARTMODE;
   c.partPeriod = RG_SPEC_PARTPERIOD; c.partJitter = RG_SPEC_PARTJITTER;
   c.churnPeriod = RG_SPEC_CHURNPERIOD; c.churnDisc = RG_SPEC_CHURNDISC; c.churnRestart = RG_SPEC_CHURNRESTART; c.churnCrash = RG_SPEC_CHURNCRASH;
   c.acctBytes = RG_SPEC_ACCTBYTES;
+}
+#endif
+template <int P, bool EXT, bool LEAN, bool COLS>
+__device__ __forceinline__ void tick_launch(const DevPtrs *Sp, HotPtrs &H, DevCfg &c, int t0, int nticks) {
+#ifdef RG_SPEC_P
+  spec_constants(c);
 #endif
 
   __shared__ WaveCtr sctr[4];
@@ -1365,7 +1378,7 @@ __device__ __forceinline__ void tick_launch(const DevPtrs *Sp, HotPtrs &H, DevCf
 // a long launch.  A span of a few ticks is bound by the instructions of its set-up, its one or two passes and its
 // wind-up, which cost a wave the same whether it holds one group or twelve: hence few, full waves, about one per SIMD.
 // The window's groups are at most 256 apart, so the uniform base + 32-bit lane offset addressing of tick_span holds.
-template <int P, bool EXT, bool COLS>
+template <int P, bool EXT, bool LEAN, bool COLS>
 __device__ __forceinline__ void due_launch(const DevPtrs *Sp, const HotPtrs &H, const DevCfg &c, int t0, int nticks) {
   constexpr int GWMAX = GrpN<P>::GWMAX;
   __shared__ WaveCtr dctr[4];
@@ -1374,12 +1387,20 @@ __device__ __forceinline__ void due_launch(const DevPtrs *Sp, const HotPtrs &H, 
   const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
   WaveCtr *w = &dctr[wave];
   if (lane < RG_WAVE_CTR_SLOTS) w->c[lane] = 0;
-  const long long first = (long long)blockIdx.x * c.dueWin;        // the window's first group
+  // c.dueSplit blocks share a window: block r of them takes rounds r, r + c.dueSplit, ...  In a one-tick launch of the
+  // benchmark workload a window has 41 +- 6 due groups, one round of 48 for most blocks; the second block of a window runs
+  // the surplus of the others at the same time instead of after it (and ends at once when there is none).
+  const long long first = (long long)((int)blockIdx.x / c.dueSplit) * c.dueWin;        // the window's first group
+  const int share = (int)blockIdx.x % c.dueSplit;
   const int tEnd = t0 + nticks;
   const int i = (int)threadIdx.x;
-  int wk = 0x7fffffff;
-  if (i < c.dueWin && first + i < c.G) wk = Sp->wake[first + i];
-  const u64 m = __builtin_amdgcn_ballot_w64(wk < tEnd);
+  // due when the launch began: not run yet and waking inside it, or already run by another block of this launch
+  bool due = false;
+  if (i < c.dueWin && first + i < c.G) {
+    const u64 pr = *(const u64 *)&RG_WAKE(*Sp, first + i);
+    due = (int)(unsigned)pr < tEnd || (int)(unsigned)(pr >> 32) == tEnd;
+  }
+  const u64 m = __builtin_amdgcn_ballot_w64(due);
   if (lane == 0) waveDue[wave] = (int)__builtin_popcountll(m);
   __syncthreads();
   int before = 0, nDue = 0;
@@ -1387,7 +1408,7 @@ __device__ __forceinline__ void due_launch(const DevPtrs *Sp, const HotPtrs &H, 
   for (int q = 0; q < 4; q++) { const int n = waveDue[q]; before += q < wave ? n : 0; nDue += n; }
   if ((m >> lane) & 1ull) pick[before + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;   // the k-th due group of the window
   __syncthreads();
-  for (int b0 = 0; b0 < nDue; b0 += 4 * GWMAX) {
+  for (int b0 = share * 4 * GWMAX; b0 < nDue; b0 += c.dueSplit * 4 * GWMAX) {
     const int nb = nDue - b0 < 4 * GWMAX ? nDue - b0 : 4 * GWMAX;  // groups of this round, shared out evenly
     const int per = (nb + 3) >> 2;
     const int lo = b0 + wave * per, hi = b0 + ((wave + 1) * per < nb ? (wave + 1) * per : nb);
@@ -1395,7 +1416,7 @@ __device__ __forceinline__ void due_launch(const DevPtrs *Sp, const HotPtrs &H, 
     const int k = lo + lane / P;
     const bool v = lane / P < GWMAX && k < hi;
     const int off = pick[v ? k : lo];                              // lanes without a group look at the wave's first one and store nothing
-    tick_span<P, EXT, false, COLS, true>(Sp, H, c, (int)first, t0, nticks, w, nullptr, nullptr, off, v);
+    tick_span<P, EXT, LEAN, COLS, true>(Sp, H, c, (int)first, t0, nticks, w, nullptr, nullptr, off, v);
   }
   __syncthreads();
   if (lane < RG_WAVE_CTR_SLOTS && w->c[lane]) atomicAdd((unsigned long long *)&Sp->counters[lane], (unsigned long long)w->c[lane]);
@@ -1403,17 +1424,29 @@ __device__ __forceinline__ void due_launch(const DevPtrs *Sp, const HotPtrs &H, 
 
 // (the extended instantiation carries the schedule's and the apply ring's code and is not asked to fit 4 waves per SIMD)
 #ifdef RG_SPEC_P
+#ifndef RG_DUE_WAVES
+#define RG_DUE_WAVES 2
+#endif
 extern "C" __global__ __launch_bounds__(256, RG_SPEC_EXT ? 2 : RG_TICK_WAVES) void k_tick_spec(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
   tick_launch<RG_SPEC_P, RG_SPEC_EXT != 0, RG_SPEC_LEAN != 0, RG_SPEC_COLS != 0>(Sp, H, c, t0, nticks);
+}
+// the due launch of the same configuration (about one wave per SIMD is busy: registers are worth more to it than occupancy)
+extern "C" __global__ __launch_bounds__(256, RG_DUE_WAVES) void k_tick_spec_due(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
+  spec_constants(c);
+  due_launch<RG_SPEC_P, RG_SPEC_EXT != 0, RG_SPEC_LEAN != 0, RG_SPEC_COLS != 0>(Sp, H, c, t0, nticks);
 }
 #else
 template <int P, bool EXT, bool LEAN, bool COLS>
 __global__ __launch_bounds__(256, EXT ? 2 : RG_TICK_WAVES) void k_tick(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
   tick_launch<P, EXT, LEAN, COLS>(Sp, H, c, t0, nticks);
 }
+// (a due launch keeps about one wave per SIMD busy: registers are worth more to it than occupancy)
+#ifndef RG_DUE_WAVES
+#define RG_DUE_WAVES 2
+#endif
 template <int P, bool EXT, bool COLS>
-__global__ __launch_bounds__(256, EXT ? 2 : RG_TICK_WAVES) void k_tick_due(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
-  due_launch<P, EXT, COLS>(Sp, H, c, t0, nticks);
+__global__ __launch_bounds__(256, RG_DUE_WAVES) void k_tick_due(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
+  due_launch<P, EXT, false, COLS>(Sp, H, c, t0, nticks);
 }
 #endif
 

@@ -31,13 +31,17 @@ def _trace(capfd):
     return [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("raftgpu: k_tick")]
 
 
-@pytest.mark.parametrize("kw,groups,window", [(LOSSY, 700, 0), (LOSSY, 700, 64), (CHURN, 300, 7), (THREE, 2000, 0), (THREE, 150, 64)])
-def test_runs_of_due_launches_between_reads(monkeypatch, capfd, kw, groups, window):
+@pytest.mark.parametrize("kw,groups,window,split", [(LOSSY, 700, 0, 0), (LOSSY, 700, 64, 1), (CHURN, 300, 7, 0), (THREE, 2000, 0, 0), (THREE, 150, 64, 0),
+                                                    (LOSSY, 6000, 256, 8), (THREE, 9000, 200, 3)])
+def test_runs_of_due_launches_between_reads(monkeypatch, capfd, kw, groups, window, split):
     """Stretches of short launches with nothing read in between (so the skipped groups stay behind for the whole
-    stretch), cut by long launches that find lagging groups; window 64: every wave sees more due groups than one pass holds."""
+    stretch), cut by long launches that find lagging groups; large windows: more due groups than one round of a block
+    holds; split: several blocks share a window's rounds and must agree on its due groups whichever of them runs first."""
     monkeypatch.setenv("RAFTGPU_TRACE_LAUNCH", "1")
     if window:
         monkeypatch.setenv("RAFTGPU_DUE_WIN", str(window))
+    if split:
+        monkeypatch.setenv("RAFTGPU_DUE_SPLIT", str(split))
     o, e = _pair(n_groups=groups, **kw)
     rng = random.Random(groups)
     t = 0
