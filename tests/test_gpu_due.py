@@ -107,7 +107,7 @@ def test_host_verbs_between_due_launches(monkeypatch, capfd):
                     want = r
                 else:
                     assert r == want, (verb, g, p)
-        n = rng.choice([1, 1, 1, 2, 4])
+        n = rng.choice([1, 1, 1, 2, 8])
         o.step(n)
         e.step(n)
     tr = _trace(capfd)

@@ -14,9 +14,13 @@ KW = dict(n_peers=5, log_cap=256, seed=2, req_drop_permille=100, reply_drop_perm
 
 
 def _free_bytes():
-    """Free device memory as the driver reports it (hipMemGetInfo)."""
-    import torch
-    return torch.cuda.mem_get_info(0)[0]
+    """Free device memory as the driver reports it: hipMemGetInfo of the HIP runtime the library itself is linked
+    against (already loaded with it; no second runtime comes into the process)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
 
 
 def _pair(groups, ticks, **over):
