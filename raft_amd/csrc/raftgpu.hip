@@ -114,6 +114,7 @@ struct rg_engine {
   std::mutex mu;
   // staging
   HostCmd *dCmd, *hCmd; size_t dCmdCap;     // device and pinned host staging of host commands
+  StartIn *dIn, *hIn; StartOut *dOut, *hOut; size_t startCap;   // the same for rg_start_batch's compact records
   std::vector<unsigned> cmdStamp; std::vector<int> cmdSeen; unsigned cmdEpoch;   // per group: batch that last named it, and how often so far
   // the tick kernel compiled for this engine's configuration (rg_specialize), and what it was compiled for
   bool specWanted;
@@ -284,6 +285,10 @@ static void free_engine(rg_engine *e) {
   for (void *p : e->allocs) hipFree(p);
   if (e->dCmd) hipFree(e->dCmd);
   if (e->hCmd) hipHostFree(e->hCmd);
+  if (e->dIn) hipFree(e->dIn);
+  if (e->dOut) hipFree(e->dOut);
+  if (e->hIn) hipHostFree(e->hIn);
+  if (e->hOut) hipHostFree(e->hOut);
   if (e->ownStream) hipStreamDestroy(e->ownStream);
   if (e->specMod) hipModuleUnload(e->specMod);
   if (e->comm) comm_release(e->comm);
@@ -943,9 +948,52 @@ extern "C" int rg_start(rg_engine *e, int32_t g, int32_t p, uint64_t cmd, int32_
   return RG_OK;
 }
 
+static int ensure_start_buf(rg_engine *e, size_t n) {
+  if (n <= e->startCap) return RG_OK;
+  if (e->dIn) hipFree(e->dIn);
+  if (e->dOut) hipFree(e->dOut);
+  if (e->hIn) hipHostFree(e->hIn);
+  if (e->hOut) hipHostFree(e->hOut);
+  e->dIn = nullptr; e->dOut = nullptr; e->hIn = nullptr; e->hOut = nullptr; e->startCap = 0;
+  const size_t cap = std::max<size_t>(n, 1024);
+  if (hipMalloc((void **)&e->dIn, cap * sizeof(StartIn)) != hipSuccess || hipMalloc((void **)&e->dOut, cap * sizeof(StartOut)) != hipSuccess ||
+      hipHostMalloc((void **)&e->hIn, cap * sizeof(StartIn), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void **)&e->hOut, cap * sizeof(StartOut), hipHostMallocDefault) != hipSuccess) return RG_ERR_NOMEM;   // (freed by the next call or rg_destroy)
+  e->startCap = cap;
+  return RG_OK;
+}
+
 extern "C" int rg_start_batch(rg_engine *e, rg_start_req *reqs, int64_t n) {
   LOCK(e);
   if (n < 0 || (n > 0 && !reqs)) return RG_ERR_ARG;
+  if (n == 0) return RG_OK;
+  // The common batch -- every group named at most once -- goes in one pass over the requests: 16 bytes per Start to the
+  // device, one kernel, 16 bytes back.  A batch that names a group twice takes the general path below, which keeps the
+  // calls on one group in order.
+  if (n <= 0x7fffffff && ensure_start_buf(e, (size_t)n) == RG_OK) {
+    if (e->cmdStamp.size() != (size_t)e->G) { e->cmdStamp.assign((size_t)e->G, 0u); e->cmdSeen.assign((size_t)e->G, 0); e->cmdEpoch = 0; }
+    if (++e->cmdEpoch == 0) { std::fill(e->cmdStamp.begin(), e->cmdStamp.end(), 0u); e->cmdEpoch = 1; }
+    bool once = true;
+    for (int64_t i = 0; i < n; i++) {
+      const int g = reqs[i].group, p = reqs[i].peer;
+      if (g < 0 || g >= e->G || p < 0 || p >= e->P) return RG_ERR_RANGE;
+      if (e->cmdStamp[g] == e->cmdEpoch) { once = false; break; }
+      e->cmdStamp[g] = e->cmdEpoch;
+      e->hIn[i].group = g; e->hIn[i].peer = p; e->hIn[i].cmd = reqs[i].command;
+    }
+    if (once) {
+      int rs = settle_client(e);
+      if (rs == RG_OK) rs = run_derive(e);
+      if (rs != RG_OK) return rs;
+      HIPCHK(hipMemcpyAsync(e->dIn, e->hIn, (size_t)n * sizeof(StartIn), hipMemcpyHostToDevice, e->stream));
+      hipLaunchKernelGGL(k_start_batch, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, e->stream, e->S, e->dc, e->PP, e->dIn, e->dOut, (int)n);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(e->hOut, e->dOut, (size_t)n * sizeof(StartOut), hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      for (int64_t i = 0; i < n; i++) { reqs[i].index = e->hOut[i].index; reqs[i].term = e->hOut[i].term; reqs[i].is_leader = e->hOut[i].isLeader; }
+      return RG_OK;
+    }
+  }
   int rc = ensure_cmd_buf(e, (size_t)n);
   if (rc != RG_OK) return rc;
   HostCmd *v = e->hCmd;

@@ -49,6 +49,37 @@ __global__ void k_host_cmds(DevPtrs S, DevCfg c, int PP, HostCmd *cmds, int n, i
   if (threadIdx.x < RG_N_COUNTERS && sctr.c[threadIdx.x]) atomicAdd((unsigned long long *)&S.counters[threadIdx.x], (unsigned long long)sctr.c[threadIdx.x]);
 }
 
+// Start (raft.go:344-364) for a batch that names every group at most once: 16 bytes in and 16 bytes out per call, which is
+// what crosses PCIe (the general command record is 40 bytes each way).
+struct StartIn { int group, peer; u64 cmd; };
+struct StartOut { int index, term, isLeader, pad; };
+__global__ void k_start_batch(DevPtrs S, DevCfg c, int PP, const StartIn *in, StartOut *out, int n) {
+  __shared__ WaveCtr sctr;
+  if (threadIdx.x < RG_N_COUNTERS) sctr.c[threadIdx.x] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const StartIn q = in[i];
+    const int g = q.group, p = q.peer;
+    const long long gl = (long long)g * PP + p;
+    const Rows lg = rows_of(S.logRows, c, g), sn = rows_of(S.snapRows, c, g);
+    int coldLocal[CD_N];
+    LaneT<int *> r; r.cold = coldLocal; r.cs = 1; r.load(S, gl);
+    unsigned gfl = 0;
+    StartOut o; o.term = r.term; o.isLeader = r.isLeader() ? 1 : 0; o.pad = 0;
+    o.index = start_cmd(r, lg, sn, p, c.L, q.cmd, gfl, &sctr);
+    if (o.index < 0) o.isLeader = 0;
+    else {                                            // only an accepted Start changes anything
+      r.store(S, gl);
+      RG_WAKE(S, g) = 0;
+    }
+    if (gfl) atomicOr(&S.gflags[g], gfl);
+    out[i] = o;
+  }
+  __syncthreads();
+  if (threadIdx.x < RG_N_COUNTERS && sctr.c[threadIdx.x]) atomicAdd((unsigned long long *)&S.counters[threadIdx.x], (unsigned long long)sctr.c[threadIdx.x]);
+}
+
 // RequestVote handler, raft.go:200-232, one request per thread (distinct groups per launch)
 __global__ void k_rpc_vote(DevPtrs S, DevCfg c, int PP, const int *groups, const int *peers, const int *order, int n,
                            const rg_vote_args *args, rg_vote_reply *replies, int now) {

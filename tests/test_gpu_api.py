@@ -113,6 +113,13 @@ def test_start_batch_drain_and_snapshots():
             want = o.start_batch(groups, peers, more)
             idx, term, lead = e.start_batch_arrays(np.array(groups), np.array(peers), np.array(more, dtype=np.uint64))
             assert want == [(int(i), int(t), bool(l)) for i, t, l in zip(idx, term, lead)]
+        # every group once: the one-pass form of the call (16 bytes per Start each way), leaders and refusing peers mixed
+        once = [int(g) for g in rng.permutation(40)]
+        pe = [int(p) for p in rng.integers(0, 2, size=40)]
+        cm = [int(c) for c in rng.integers(1, 2 ** 62, size=40)]
+        want = o.start_batch(once, pe, cm)
+        assert want == e.start_batch(once, pe, cm)
+        assert any(l for _, _, l in want) and any(not l for _, _, l in want)
         o.step(15)
         e.step(15)
         assert not diff_states(o, e)
