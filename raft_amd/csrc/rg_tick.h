@@ -1291,9 +1291,14 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     const unsigned tot = (unsigned)(__builtin_readcyclecounter() - _dstamp0);
     if (G.lane == 0) {
       atomicAdd(&w->c[40 + 9], 1u); atomicAdd(&w->c[40 + 10], ng); atomicAdd(&w->c[40 + 15], (unsigned)(__builtin_amdgcn_s_memrealtime() - _dreal0));
-      if (tot > 60000u) atomicAdd(&w->c[40 + 12], 1u);
-      if (tot > 120000u) atomicAdd(&w->c[40 + 13], 1u);
-      if (tot > 200000u) atomicAdd(&w->c[40 + 14], 1u);
+#ifndef RG_DST_T1
+#define RG_DST_T1 60000u
+#define RG_DST_T2 120000u
+#define RG_DST_T3 200000u
+#endif
+      if (tot > RG_DST_T1) atomicAdd(&w->c[40 + 12], 1u);
+      if (tot > RG_DST_T2) atomicAdd(&w->c[40 + 13], 1u);
+      if (tot > RG_DST_T3) atomicAdd(&w->c[40 + 14], 1u);
     }
   }
 #endif
