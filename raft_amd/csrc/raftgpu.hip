@@ -660,15 +660,15 @@ static int launch_kernel(rg_engine *e, int n_ticks, int *relay, int *relayStage,
       const bool leanD = dc.churnPeriod == 0 && dc.startMode == RG_START_ONE && !extD;
       if (e->specDueFn && e->specExt == extD && e->specLean == leanD && spec_same(e->specFor, dc)) {
         int t0 = (int)e->now, n = n_ticks;
-        void *params[] = {(void *)&dS, (void *)&H, (void *)&dc, (void *)&t0, (void *)&n};
+        void *params[] = {(void *)&e->S, (void *)&H, (void *)&dc, (void *)&t0, (void *)&n};
         HIPCHK(hipModuleLaunchKernel(e->specDueFn, dblocks, 1, 1, 256, 1, 1, 0, e->stream, params, nullptr));
         e->lazy = true;
         return RG_OK;
       }
     }
 #define DUE_LAUNCH2(PEERS, COLS) do { \
-    if (extD) hipLaunchKernelGGL((k_tick_due<PEERS, true, COLS>), dim3(dblocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); \
-    else hipLaunchKernelGGL((k_tick_due<PEERS, false, COLS>), dim3(dblocks), dim3(256), 0, e->stream, dS, H, dc, (int)e->now, n_ticks); } while (0)
+    if (extD) hipLaunchKernelGGL((k_tick_due<PEERS, true, COLS>), dim3(dblocks), dim3(256), 0, e->stream, e->S, H, dc, (int)e->now, n_ticks); \
+    else hipLaunchKernelGGL((k_tick_due<PEERS, false, COLS>), dim3(dblocks), dim3(256), 0, e->stream, e->S, H, dc, (int)e->now, n_ticks); } while (0)
 #define DUE_LAUNCH(PEERS) do { if (e->cols) DUE_LAUNCH2(PEERS, true); else DUE_LAUNCH2(PEERS, false); } while (0)
 #ifdef RG_ONLY_P                                   // diagnostic builds: one peer count, a tenth of the compile time
     if (e->P != RG_ONLY_P) return RG_ERR_ARG;

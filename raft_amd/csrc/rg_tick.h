@@ -1436,9 +1436,11 @@ extern "C" __global__ __launch_bounds__(256, RG_SPEC_EXT ? 2 : RG_TICK_WAVES) vo
   tick_launch<RG_SPEC_P, RG_SPEC_EXT != 0, RG_SPEC_LEAN != 0, RG_SPEC_COLS != 0>(Sp, H, c, t0, nticks);
 }
 // the due launch of the same configuration (about one wave per SIMD is busy: registers are worth more to it than occupancy)
-extern "C" __global__ __launch_bounds__(256, RG_DUE_WAVES) void k_tick_spec_due(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
+// (the pointer block comes by value here: a span of a due launch begins with a chain of dependent loads, and this takes the
+// first link out of it)
+extern "C" __global__ __launch_bounds__(256, RG_DUE_WAVES) void k_tick_spec_due(DevPtrs S, HotPtrs H, DevCfg c, int t0, int nticks) {
   spec_constants(c);
-  due_launch<RG_SPEC_P, RG_SPEC_EXT != 0, RG_SPEC_LEAN != 0, RG_SPEC_COLS != 0>(Sp, H, c, t0, nticks);
+  due_launch<RG_SPEC_P, RG_SPEC_EXT != 0, RG_SPEC_LEAN != 0, RG_SPEC_COLS != 0>(&S, H, c, t0, nticks);
 }
 #else
 template <int P, bool EXT, bool LEAN, bool COLS>
@@ -1450,8 +1452,8 @@ __global__ __launch_bounds__(256, EXT ? 2 : RG_TICK_WAVES) void k_tick(const Dev
 #define RG_DUE_WAVES 2
 #endif
 template <int P, bool EXT, bool COLS>
-__global__ __launch_bounds__(256, RG_DUE_WAVES) void k_tick_due(const DevPtrs *Sp, HotPtrs H, DevCfg c, int t0, int nticks) {
-  due_launch<P, EXT, false, COLS>(Sp, H, c, t0, nticks);
+__global__ __launch_bounds__(256, RG_DUE_WAVES) void k_tick_due(DevPtrs S, HotPtrs H, DevCfg c, int t0, int nticks) {
+  due_launch<P, EXT, false, COLS>(&S, H, c, t0, nticks);
 }
 #endif
 
