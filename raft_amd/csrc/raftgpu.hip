@@ -285,8 +285,6 @@ static void free_engine(rg_engine *e) {
   for (void *p : e->allocs) hipFree(p);
   if (e->dCmd) hipFree(e->dCmd);
   if (e->hCmd) hipHostFree(e->hCmd);
-  if (e->dIn) hipFree(e->dIn);
-  if (e->dOut) hipFree(e->dOut);
   if (e->hIn) hipHostFree(e->hIn);
   if (e->hOut) hipHostFree(e->hOut);
   if (e->ownStream) hipStreamDestroy(e->ownStream);
@@ -950,15 +948,15 @@ extern "C" int rg_start(rg_engine *e, int32_t g, int32_t p, uint64_t cmd, int32_
 
 static int ensure_start_buf(rg_engine *e, size_t n) {
   if (n <= e->startCap) return RG_OK;
-  if (e->dIn) hipFree(e->dIn);
-  if (e->dOut) hipFree(e->dOut);
   if (e->hIn) hipHostFree(e->hIn);
   if (e->hOut) hipHostFree(e->hOut);
   e->dIn = nullptr; e->dOut = nullptr; e->hIn = nullptr; e->hOut = nullptr; e->startCap = 0;
   const size_t cap = std::max<size_t>(n, 1024);
-  if (hipMalloc((void **)&e->dIn, cap * sizeof(StartIn)) != hipSuccess || hipMalloc((void **)&e->dOut, cap * sizeof(StartOut)) != hipSuccess ||
-      hipHostMalloc((void **)&e->hIn, cap * sizeof(StartIn), hipHostMallocDefault) != hipSuccess ||
-      hipHostMalloc((void **)&e->hOut, cap * sizeof(StartOut), hipHostMallocDefault) != hipSuccess) return RG_ERR_NOMEM;   // (freed by the next call or rg_destroy)
+  // pinned host memory the device reads and writes in place (dIn / dOut: the device's addresses of the same buffers)
+  if (hipHostMalloc((void **)&e->hIn, cap * sizeof(StartIn), hipHostMallocMapped) != hipSuccess ||
+      hipHostMalloc((void **)&e->hOut, cap * sizeof(StartOut), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&e->dIn, e->hIn, 0) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&e->dOut, e->hOut, 0) != hipSuccess) return RG_ERR_NOMEM;   // (freed by the next call or rg_destroy)
   e->startCap = cap;
   return RG_OK;
 }
@@ -985,10 +983,10 @@ extern "C" int rg_start_batch(rg_engine *e, rg_start_req *reqs, int64_t n) {
       int rs = settle_client(e);
       if (rs == RG_OK) rs = run_derive(e);
       if (rs != RG_OK) return rs;
-      HIPCHK(hipMemcpyAsync(e->dIn, e->hIn, (size_t)n * sizeof(StartIn), hipMemcpyHostToDevice, e->stream));
+      // the kernel reads the requests from, and writes the answers to, the pinned host buffers themselves: one operation on
+      // the stream instead of copy + kernel + copy
       hipLaunchKernelGGL(k_start_batch, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, e->stream, e->S, e->dc, e->PP, e->dIn, e->dOut, (int)n);
       HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(e->hOut, e->dOut, (size_t)n * sizeof(StartOut), hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
       for (int64_t i = 0; i < n; i++) { reqs[i].index = e->hOut[i].index; reqs[i].term = e->hOut[i].term; reqs[i].is_leader = e->hOut[i].isLeader; }
       return RG_OK;
