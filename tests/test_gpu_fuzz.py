@@ -145,6 +145,11 @@ def _run(seed, tweak=None, until=1500):
             g, p = rk.randrange(kw["n_groups"]), rk.randrange(kw["n_peers"])
             o.kill(g, p)
             e.kill(g, p)
+        if rk.random() < 0.05:                      # Start on many groups in one call, each group once
+            gs = rk.sample(range(kw["n_groups"]), rk.randrange(1, kw["n_groups"] + 1))
+            ps = [rk.randrange(kw["n_peers"]) for _ in gs]
+            cs = [900000 + 1000 * t + i for i in range(len(gs))]
+            assert o.start_batch(gs, ps, cs) == e.start_batch(gs, ps, cs)
         if rng.random() < 0.2:                      # host verbs between launches
             g, p = rng.randrange(kw["n_groups"]), rng.randrange(kw["n_peers"])
             verb = rng.choice(["start", "disconnect", "connect", "crash", "restart", "move_blob", "vote", "append", "reset_group", "group_rates", "drain"])
