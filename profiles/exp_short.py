@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""One-tick launches under different loads: every group crashed (the launch overhead), an idle lossless net, the benchmark
+workload at several window sizes and group counts (wall time per launch, and HIP events around each launch).
+usage: python profiles/exp_short.py"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["RAFTGPU_DUE_MAX_TICKS"] = "1000"
 from raft_amd import Engine, _abi
 import numpy as np
