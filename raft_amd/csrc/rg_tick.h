@@ -528,7 +528,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   } else tg = next_event(t0);
   if (!valid) tg = 0x7fffffff;
   DSTAMP(3);
-  while (wave_any(tg < tEnd)) {
+  if (wave_any(tg < tEnd)) do {
     const bool run = tg < tEnd;            // the lane's group runs its tick tg in this pass
     SECTION_COUNT(w, 14);
     if (wave_any(run && G.peer == 0)) { if (run && G.peer == 0 && G.inWave) SECTION_COUNT_LANE(w, 15); }
@@ -706,7 +706,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
       STAMP(1);
       if (wave_any(pend)) { start = turn_start(key, t, P); myPos = peer - start + (peer < start ? P : 0); }
 
-      while (wave_any(pend)) {
+      if (wave_any(pend)) do {
         SECTION_COUNT(w, 0);
         const unsigned pm = G.ballot(pend);
         const unsigned pmHi = pm >> start;                   // cyclic order from this tick's start
@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           STAMP(8);
         }
         if (isS) pend = false;
-      }
+      } while (wave_any(pend));
       if (specEl) r.elNext = now + RG_ELECTION_PERIOD_MS + RG_ELECTION_LEADER_EXTRA_MS + sleep_slack(key, peerL, now);
       if (specMon) r.monNext = now + RG_MONITOR_POLL_MS;
     }
@@ -1230,7 +1230,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
       if (run) tg = ne;
     }
     STAMP(11);
-  }
+  } while (wave_any(tg < tEnd));
   DSTAMP(4);
   client_starts(valid, tEnd - 1);          // Starts and wake-ups the groups skipped towards the end of the launch
   DSTAMP(5);
