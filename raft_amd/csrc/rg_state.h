@@ -128,7 +128,7 @@ struct WaveCtr { unsigned c[RG_WAVE_CTR_SLOTS]; };
 #define DSTAMP_INIT do { } while (0)
 #endif
 
-enum { CD_SNAPTERM = 0, CD_SNAPVOTE, CD_SNAPLEN, CD_RNGCTR, CD_ROUNDSEQ, CD_AH_LO, CD_AH_HI, CD_APPLIED, CD_SNAPSYNC, CD_LASTTERM, CD_FIRSTOWN, CD_CTERM, CD_N };
+enum { CD_SNAPTERM = 0, CD_SNAPVOTE, CD_SNAPLEN, CD_RNGCTR, CD_ROUNDSEQ, CD_AH_LO, CD_AH_HI, CD_SNAPSYNC, CD_LASTTERM, CD_FIRSTOWN, CD_CTERM, CD_N };
 
 typedef __attribute__((address_space(3))) int lds_int;
 
@@ -136,8 +136,9 @@ typedef __attribute__((address_space(3))) int lds_int;
 template <typename CP>
 struct LaneT {
   int term, vote, commit, logLen, timer, timeout, hbTimer, elNext, monNext;
+  int applied;                   // lastApplied: looked at in every pass (is there anything to apply?)
   unsigned flags;
-  // Words touched only by events (persist, draws, round numbering, apply cursor and digest, and three caches of
+  // Words touched only by events (persist, draws, round numbering, the apply digest, and three caches of
   // log words rebuilt by k_derive after host writes: term of the last entry, first index from which every entry
   // carries the current term, term of the entry at commitIndex) live outside the register
   // file: in the tick kernel in LDS, one 256-lane row per word (cs = 256), so any lane of the group can also read
@@ -163,14 +164,14 @@ struct LaneT {
   __device__ void kill() { if (!(flags & F_DEAD)) flags |= F_DEAD | F_ZOMBIE; }
 
   __device__ void load(const DevPtrs &S, long long gl) {
-    term = S.term[gl]; vote = S.vote[gl]; flags = (unsigned)S.flags[gl]; commit = S.commit[gl]; cd(CD_APPLIED) = S.applied[gl];
+    term = S.term[gl]; vote = S.vote[gl]; flags = (unsigned)S.flags[gl]; commit = S.commit[gl]; applied = S.applied[gl];
     logLen = S.logLen[gl]; timer = S.timer[gl]; timeout = S.timeout[gl]; hbTimer = S.hbTimer[gl]; elNext = S.elNext[gl];
     monNext = S.monNext[gl]; cd(CD_RNGCTR) = S.rngCtr[gl]; cd(CD_ROUNDSEQ) = S.roundSeq[gl];
     cd(CD_SNAPTERM) = S.snapTerm[gl]; cd(CD_SNAPVOTE) = S.snapVote[gl]; cd(CD_SNAPLEN) = S.snapLen[gl]; cd(CD_SNAPSYNC) = S.snapSync[gl];
     cd(CD_LASTTERM) = S.lastTerm[gl]; cd(CD_FIRSTOWN) = S.firstOwn[gl]; cd(CD_CTERM) = S.commitTerm[gl]; setApplyHash(S.applyHash[gl]);
   }
   __device__ void store(const DevPtrs &S, long long gl) const {
-    S.term[gl] = term; S.vote[gl] = vote; S.flags[gl] = (int)flags; S.commit[gl] = commit; S.applied[gl] = cd(CD_APPLIED);
+    S.term[gl] = term; S.vote[gl] = vote; S.flags[gl] = (int)flags; S.commit[gl] = commit; S.applied[gl] = applied;
     S.logLen[gl] = logLen; S.timer[gl] = timer; S.timeout[gl] = timeout; S.hbTimer[gl] = hbTimer; S.elNext[gl] = elNext;
     S.monNext[gl] = monNext; S.rngCtr[gl] = cd(CD_RNGCTR); S.roundSeq[gl] = cd(CD_ROUNDSEQ);
     S.snapTerm[gl] = cd(CD_SNAPTERM); S.snapVote[gl] = cd(CD_SNAPVOTE); S.snapLen[gl] = cd(CD_SNAPLEN); S.snapSync[gl] = cd(CD_SNAPSYNC);
@@ -288,7 +289,7 @@ __device__ static inline void make_peer(LN &r, const Rows &lg, const Rows &sn, i
   r.flags &= ~(F_DEAD | F_ZOMBIE | F_STATE_MASK | F_STOP | F_CNT_MASK | F_MONALIVE | F_FIRST | F_RESTART | F_CDIRTY);
   r.term = 0; r.vote = -1;
   *lg.termp(0, col) = 0; *lg.cmdp(0, col) = 0;
-  r.logLen = 1; r.commit = 0; r.cd(CD_APPLIED) = 0; r.timer = now; r.hbTimer = now;
+  r.logLen = 1; r.commit = 0; r.applied = 0; r.timer = now; r.hbTimer = now;
   r.cd(CD_LASTTERM) = 0; r.cd(CD_CTERM) = 0;
   if (r.has(F_SNAPHAS) && r.cd(CD_SNAPLEN) >= 1) {
     r.term = r.cd(CD_SNAPTERM); r.vote = r.cd(CD_SNAPVOTE);

@@ -224,8 +224,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
 #define nextRow(i) nextBlk[mOff + (unsigned)(i)]
 #define matchRow(i) matchBlk[mOff + (unsigned)(i)]
   u64 *const recBlk = H.applyRec + (size_t)g0 * L;
-  unsigned gLocL = gLoc;                 // laundered once per pass: offsets derived from it are recomputed, not kept
-  int peerL = peer;
+  const unsigned gLocL = gLoc;
+  const int peerL = peer;
 #define rOff (gLocL * (unsigned)L)
 #define rec(i) recBlk[rOff + (unsigned)(i)]
   u64 key = sm64(c.seedKey ^ (u64)(c.groupBase + g));
@@ -236,7 +236,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     if (H.netCfg) { const unsigned nw = H.netCfg[gq]; if (nw >> 31) net = unpack_rates(nw); }
   }
 
-  __shared__ int coldLds[CD_N + 9 + (EXT ? 4 : 0)][256];   // peer words, 5 group words, the checked-apply cursor, the lane's cache of one leader's nextIndex / matchIndex pair, per-lane byte sums
+  __shared__ int coldLds[CD_N + (EXT ? 4 : 0)][256];   // the peers' event-only words; extended instantiation: per-lane byte sums, the schedule's position and registers
   __shared__ int churnNext[GPB];                              // per group: its next churn tick (written by all its lanes alike)
   // The last RING entries each peer wrote to its log, staged in LDS: a follower copies a leader's fresh entries,
   // and every peer applies its fresh entries, without a trip to HBM.  Slot = index % RING, tagged with the index; HBM is written through and stays authoritative.
@@ -250,11 +250,12 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   LaneT<lds_int *> r;
   r.cold = (lds_int *)&coldLds[0][threadIdx.x]; r.cs = 256;
   r.load(*Sp, gl);                       // tail lanes read a valid slot and never write it back
-#define gStartSeq coldLds[CD_N][threadIdx.x]
-#define gPartEpoch coldLds[CD_N + 1][threadIdx.x]
+  // The group's words, a copy in each of its lanes, the apply cursor, the cursor of the checked applies and the lane's cached
+  // matrix pair are looked at in every pass or every round: they stay in registers (as LDS rows, each look was a trip through
+  // the LDS pipe in the middle of a chain of dependent instructions: 40.9 against 39.7 ms).
+  int gStartSeq, gPartEpoch, gNextStart, gPartNext, gRecMax;
   gStartSeq = stIn ? stIn[gLoc] : Sp->startSeq[gq]; gPartEpoch = stIn ? stIn[GPBPAD + gLoc] : Sp->partEpoch[gq];
-#define lVerified coldLds[CD_N + 5][threadIdx.x]
-  lVerified = r.cd(CD_APPLIED);
+  int lVerified = r.applied;
 #ifdef RG_DSTAMPS
   WAIT_LOADS();
 #endif
@@ -263,21 +264,16 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     const int sent = G.gsum(valid ? r.cd(CD_ROUNDSEQ) : 0);
     if (valid && peer == 0) stOut[5 * GPBPAD + gLoc] = sent;
   }
-  if constexpr (EXT) { coldLds[CD_N + 9][threadIdx.x] = 0; coldLds[CD_N + 10][threadIdx.x] = 0; }
-#define gSchedPos coldLds[CD_N + 11][threadIdx.x]
-#define gRegs coldLds[CD_N + 12][threadIdx.x]
+  if constexpr (EXT) { coldLds[CD_N][threadIdx.x] = 0; coldLds[CD_N + 1][threadIdx.x] = 0; }
+#define gSchedPos coldLds[CD_N + 2][threadIdx.x]
+#define gRegs coldLds[CD_N + 3][threadIdx.x]
   if constexpr (EXT) { gSchedPos = H.schedN > 0 ? Sp->schedPos[gq] : 0; gRegs = H.schedN > 0 ? Sp->schedRegs[gq] : 0xFFFF; }
-#define gPartNext coldLds[CD_N + 3][threadIdx.x]
-#define gRecMax coldLds[CD_N + 4][threadIdx.x]
   gPartNext = stIn ? stIn[2 * GPBPAD + gLoc] : Sp->partNext[gq]; gRecMax = stIn ? stIn[3 * GPBPAD + gLoc] : Sp->recMax[gq];
   unsigned gfl = 0;
   // next ticks of the periodic control events (kept as counters: no division in the loop)
   // Within a launch each lane caches the nextIndex / matchIndex words ONE leader (cOwner) keeps for it; memory is
   // written through, so the matrices in HBM stay complete for other owners, dumps and digests.
-#define cOwner coldLds[CD_N + 6][threadIdx.x]
-#define cNext coldLds[CD_N + 7][threadIdx.x]
-#define cMatch coldLds[CD_N + 8][threadIdx.x]
-  cOwner = -1; cNext = 0; cMatch = 0;
+  int cOwner = -1, cNext = 0, cMatch = 0;
   // stores to words another lane may read later are drained (vmcnt) only right before such a read
   bool storesPending = false;
 #define SYNC_STORES() do { if (storesPending) { SECTION_COUNT(w, 7); wave_fence(); storesPending = false; } } while (0)
@@ -289,7 +285,6 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   // poll behind a closed gate) are not events: their chains are caught up when the group next runs a tick
   // (catch_up) and once more when the launch ends, so every word is as the tick-by-tick order leaves it.
   const int tEnd = t0 + nticks;
-#define gNextStart coldLds[CD_N + 2][threadIdx.x]
 #define gChurnNext churnNext[gSlot]
   {
     int ns = 0x7fffffff;
@@ -344,7 +339,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
         cand = mGate < cand ? mGate : cand;
         candS = mStart < candS ? mStart : candS;
       }
-      if (r.commit > r.cd(CD_APPLIED)) { cand = from; candS = from; }   // entries committed by a host call are applied at once
+      if (r.commit > r.applied) { cand = from; candS = from; }   // entries committed by a host call are applied at once
       // The first connected leader takes the Starts only while its log has room: the Start that no longer fits goes to
       // the next leader (or to nobody), whose gate it changes, so the group runs at that Start's tick and looks again.
       if (taker && !(!LEAN && c.startMode == RG_START_ALL) && gStartSeq + (L - r.logLen) < c.startMax) {
@@ -374,12 +369,12 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   // cursor moves: lVerified trails r.applied, and the stretch between them is checked by the whole wave (one entry
   // per lane) before anything could overwrite one of its entries, and when the launch ends.
   auto verify_applied = [&](bool want) {
-    const bool need = want && valid && lVerified < r.cd(CD_APPLIED);
+    const bool need = want && valid && lVerified < r.applied;
     u64 vm = __builtin_amdgcn_ballot_w64(need);
     if (vm) {
       SECTION_COUNT(w, 12);
       SYNC_STORES();
-      const int nOwn = r.cd(CD_APPLIED) - lVerified;
+      const int nOwn = r.applied - lVerified;
       if constexpr (SHORTP) {
         const bool mine = need && nOwn <= SHORTN;
         if (mine) {
@@ -404,7 +399,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
         }
         vm &= ~__builtin_amdgcn_ballot_w64(mine);
       }
-      while (vm) {
+      if (!SHORTP || vm) do {
         const int src = (int)__builtin_ctzll(vm);
         vm &= vm - 1;
         const unsigned offB = (unsigned)__builtin_amdgcn_readlane((int)lg.off, src), rOffB = (unsigned)__builtin_amdgcn_readlane((int)rOff, src);
@@ -426,24 +421,24 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           atomicAdd((unsigned *)&coldLds[CD_AH_HI][tTid], accHi);
         }
         if (wave_any(differs) && G.lane == src) gfl |= RG_FLAG_STATE_MACHINE;
-      }
-      if (need) lVerified = r.cd(CD_APPLIED);
+      } while (vm);
+      if (need) lVerified = r.applied;
     }
   };
 
   // Client Starts of the lane's group that are due up to tick `upTo` (next_event lets a group skip the tick of a
   // Start and accounts for what the Start changes; Start() itself does not look at the clock).
   auto client_starts = [&](bool on, int upTo) {
-    for (;;) {
-      const bool startNow = c.startPeriod > 0 && on && gNextStart <= upTo && gStartSeq < c.startMax;
-      if (!(c.startPeriod > 0 && wave_any(startNow))) break;
+    if (!(c.startPeriod > 0)) return;
+    bool startNow = on && gNextStart <= upTo && gStartSeq < c.startMax;
+    if (wave_any(startNow)) do {
       // client Starts: config.go:436-451 (first connected leader) / test_test.go:697-703 (every leader)
       bool cand = startNow && valid && r.isLeader() && ((!LEAN && c.startMode == RG_START_ALL) || r.has(F_CONNECTED));
       const unsigned mAll = G.ballot(cand);
       if (startNow && mAll == 0) { do gNextStart += c.startPeriod; while (gNextStart <= upTo); }   // nobody to ask: these Starts change nothing
       if (wave_any(cand)) {
         SECTION_COUNT(w, 5);
-        if (wave_any(cand && r.logLen <= r.cd(CD_APPLIED))) verify_applied(cand && r.logLen <= r.cd(CD_APPLIED));
+        if (wave_any(cand && r.logLen <= r.applied)) verify_applied(cand && r.logLen <= r.applied);
         bool room = cand && r.logLen < L;
         const unsigned mRoom = G.ballot(room);
         unsigned below = (1u << peer) - 1u;
@@ -514,7 +509,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
         }
         storesPending = true;
       }
-    }
+      startNow = on && gNextStart <= upTo && gStartSeq < c.startMax;
+    } while (wave_any(startNow));
   };
 
   DSTAMP(2);
@@ -535,13 +531,6 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     const int t = tg;
     const int now = t * RG_TICK_MS;
     STAMP_INIT;
-    {   // Values derived from the key alone (hash partials of the seeded streams) are cheap to recompute where a
-        // rare event needs them; kept across ticks they only crowd the register file and get spilled.
-      unsigned klo = (unsigned)key, khi = (unsigned)(key >> 32);
-      asm volatile("" : "+v"(klo), "+v"(khi));
-      key = ((u64)khi << 32) | klo;
-      asm volatile("" : "+v"(peerL), "+v"(gLocL));
-    }
     if (run) catch_up(t);
     STAMP(9);
     // ------------------------------------------------------------ 1. control
@@ -771,7 +760,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
             if (wasLead && d.touch && myPos > sPos && (specEl || specMon)) { pend = true; specEl = false; specMon = false; }
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok), grantM = G.ballot(ok && d.grant);
-          if constexpr (EXT) atomicAdd((unsigned *)&coldLds[CD_N + 9][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
+          if constexpr (EXT) atomicAdd((unsigned *)&coldLds[CD_N][tid], called ? (unsigned)RG_VOTE_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_VOTE_REPLY_BYTES : 0u) : 0u);
           const int busy = G.gsum(called ? cost : 0);
           bool won = false;
           if (wantRV) {
@@ -945,7 +934,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
             }
           }
           // entries at or below the receiver's apply cursor are about to be rewritten: check them first
-          if (wave_any(ran && d.touch && d.match && nx <= r.cd(CD_APPLIED))) verify_applied(ran && d.touch && d.match && nx <= r.cd(CD_APPLIED));
+          if (wave_any(ran && d.touch && d.match && nx <= r.applied)) verify_applied(ran && d.touch && d.match && nx <= r.applied);
           {
             u64 hm = __builtin_amdgcn_ballot_w64(viaHbm);
             const bool scan = ok && b != peer && d.touch && !d.match;
@@ -1044,8 +1033,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           }
           const unsigned calledM = G.ballot(called), ranM = G.ballot(ran), okM = G.ballot(ok);
           if constexpr (EXT) {   // wire bytes: summed per target lane in LDS words of its own, added to the counters when the launch ends
-            atomicAdd((unsigned *)&coldLds[CD_N + 9][tid], called ? (unsigned)RG_APPEND_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_APPEND_REPLY_BYTES : 0u) : 0u);
-            atomicAdd((unsigned *)&coldLds[CD_N + 10][tid], (called && k > 0) ? (unsigned)k : 0u);
+            atomicAdd((unsigned *)&coldLds[CD_N][tid], called ? (unsigned)RG_APPEND_ARGS_BYTES + ((ran && (outW & NET_WIRE)) ? (unsigned)RG_APPEND_REPLY_BYTES : 0u) : 0u);
+            atomicAdd((unsigned *)&coldLds[CD_N + 1][tid], (called && k > 0) ? (unsigned)k : 0u);
           }
           const int busy = G.gsum(called ? cost : 0);
           int rTermB = 0;
@@ -1104,11 +1093,11 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     // against the record, and records the rest.  Ranges of different peers that are recorded never overlap.  Here
     // the cursor moves and new indices are recorded at once; the checks and the digest follow in verify_applied.
     {
-      const bool act = run && valid && !r.has(F_DEAD) && r.commit > r.cd(CD_APPLIED);
+      const bool act = run && valid && !r.has(F_DEAD) && r.commit > r.applied;
       if (wave_any(act)) {
         SECTION_COUNT(w, 4);
         const int cA = act ? r.commit : 0;
-        const int applied = r.cd(CD_APPLIED);
+        const int applied = r.applied;
         int pm = gRecMax, newMax = gRecMax;
         if (wave_any(cA > gRecMax)) {
 #pragma unroll
@@ -1203,7 +1192,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
         }
         if (act) {
           ctr_add(w, RG_C_ENTRIES_APPLIED, (unsigned)(r.commit - applied));
-          r.cd(CD_APPLIED) = r.commit;
+          r.applied = r.commit;
         }
         // keep the unchecked stretch short, so that a check forced by a rewrite (in the middle of a round) is one step
         if (wave_any(act && r.commit - lVerified >= RG_VERIFY_BATCH)) verify_applied(act && r.commit - lVerified >= RG_VERIFY_BATCH);
@@ -1245,8 +1234,8 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   int schedPosOut = 0, regsOut = 0;
   if constexpr (EXT) { schedPosOut = gSchedPos; regsOut = gRegs; }
   if (EXT && c.acctBytes) {
-    if (coldLds[CD_N + 9][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N + 9][threadIdx.x]);
-    if (coldLds[CD_N + 10][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 10][threadIdx.x]);
+    if (coldLds[CD_N][threadIdx.x]) ctr_add(w, RG_C_RPC_FIXED_BYTES, (unsigned)coldLds[CD_N][threadIdx.x]);
+    if (coldLds[CD_N + 1][threadIdx.x]) ctr_add(w, RG_C_AE_ENTRIES_SENT, (unsigned)coldLds[CD_N + 1][threadIdx.x]);
   }
 #undef gStartSeq
 #undef gSchedPos
