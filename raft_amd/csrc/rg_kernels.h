@@ -136,7 +136,7 @@ __global__ void k_rpc_append(DevPtrs S, DevCfg c, int PP, const int *groups, con
           rep.success = 1;
           const int base = a.prev_log_index + 1;
           for (int j = 0; j < a.n_entries; j++) { *lg.termp(base + j, p) = eterms[a.entry_off + j]; *lg.cmdp(base + j, p) = ecmds[a.entry_off + j]; }
-          if (a.n_entries > 0 && base < r.cd(CD_SNAPSYNC)) r.cd(CD_SNAPSYNC) = base;
+          if (a.n_entries > 0 && base < r.snapSync) r.snapSync = base;
           r.logLen = base + a.n_entries;
           r.cd(CD_LASTTERM) = a.n_entries > 0 ? eterms[a.entry_off + a.n_entries - 1] : a.prev_log_term;
           if (a.leader_commit > r.commit) r.commit = (r.logLen - 1 < a.leader_commit) ? r.logLen - 1 : a.leader_commit;

@@ -128,7 +128,7 @@ struct WaveCtr { unsigned c[RG_WAVE_CTR_SLOTS]; };
 #define DSTAMP_INIT do { } while (0)
 #endif
 
-enum { CD_SNAPTERM = 0, CD_SNAPVOTE, CD_SNAPLEN, CD_RNGCTR, CD_ROUNDSEQ, CD_AH_LO, CD_AH_HI, CD_SNAPSYNC, CD_LASTTERM, CD_FIRSTOWN, CD_CTERM, CD_N };
+enum { CD_SNAPTERM = 0, CD_SNAPVOTE, CD_SNAPLEN, CD_RNGCTR, CD_ROUNDSEQ, CD_AH_LO, CD_AH_HI, CD_LASTTERM, CD_FIRSTOWN, CD_CTERM, CD_N };
 
 typedef __attribute__((address_space(3))) int lds_int;
 
@@ -137,6 +137,7 @@ template <typename CP>
 struct LaneT {
   int term, vote, commit, logLen, timer, timeout, hbTimer, elNext, monNext;
   int applied;                   // lastApplied: looked at in every pass (is there anything to apply?)
+  int snapSync;                  // entries of the log the persisted copy already holds: looked at by every persist()
   unsigned flags;
   // Words touched only by events (persist, draws, round numbering, the apply digest, and three caches of
   // log words rebuilt by k_derive after host writes: term of the last entry, first index from which every entry
@@ -167,14 +168,14 @@ struct LaneT {
     term = S.term[gl]; vote = S.vote[gl]; flags = (unsigned)S.flags[gl]; commit = S.commit[gl]; applied = S.applied[gl];
     logLen = S.logLen[gl]; timer = S.timer[gl]; timeout = S.timeout[gl]; hbTimer = S.hbTimer[gl]; elNext = S.elNext[gl];
     monNext = S.monNext[gl]; cd(CD_RNGCTR) = S.rngCtr[gl]; cd(CD_ROUNDSEQ) = S.roundSeq[gl];
-    cd(CD_SNAPTERM) = S.snapTerm[gl]; cd(CD_SNAPVOTE) = S.snapVote[gl]; cd(CD_SNAPLEN) = S.snapLen[gl]; cd(CD_SNAPSYNC) = S.snapSync[gl];
+    cd(CD_SNAPTERM) = S.snapTerm[gl]; cd(CD_SNAPVOTE) = S.snapVote[gl]; cd(CD_SNAPLEN) = S.snapLen[gl]; snapSync = S.snapSync[gl];
     cd(CD_LASTTERM) = S.lastTerm[gl]; cd(CD_FIRSTOWN) = S.firstOwn[gl]; cd(CD_CTERM) = S.commitTerm[gl]; setApplyHash(S.applyHash[gl]);
   }
   __device__ void store(const DevPtrs &S, long long gl) const {
     S.term[gl] = term; S.vote[gl] = vote; S.flags[gl] = (int)flags; S.commit[gl] = commit; S.applied[gl] = applied;
     S.logLen[gl] = logLen; S.timer[gl] = timer; S.timeout[gl] = timeout; S.hbTimer[gl] = hbTimer; S.elNext[gl] = elNext;
     S.monNext[gl] = monNext; S.rngCtr[gl] = cd(CD_RNGCTR); S.roundSeq[gl] = cd(CD_ROUNDSEQ);
-    S.snapTerm[gl] = cd(CD_SNAPTERM); S.snapVote[gl] = cd(CD_SNAPVOTE); S.snapLen[gl] = cd(CD_SNAPLEN); S.snapSync[gl] = cd(CD_SNAPSYNC);
+    S.snapTerm[gl] = cd(CD_SNAPTERM); S.snapVote[gl] = cd(CD_SNAPVOTE); S.snapLen[gl] = cd(CD_SNAPLEN); S.snapSync[gl] = snapSync;
     S.lastTerm[gl] = cd(CD_LASTTERM); S.firstOwn[gl] = cd(CD_FIRSTOWN); S.commitTerm[gl] = cd(CD_CTERM); S.applyHash[gl] = applyHash();
   }
 };
@@ -232,9 +233,9 @@ __device__ static inline void persist(LN &r, int L, WaveCtr *w) {
   if (n > L) n = L;
   r.cd(CD_SNAPTERM) = r.term;
   r.cd(CD_SNAPVOTE) = r.vote;
-  if (n > r.cd(CD_SNAPSYNC)) {
-    ctr_add(w, RG_C_PERSIST_ENTRIES, (unsigned)(n - r.cd(CD_SNAPSYNC)));
-    r.cd(CD_SNAPSYNC) = n;
+  if (n > r.snapSync) {
+    ctr_add(w, RG_C_PERSIST_ENTRIES, (unsigned)(n - r.snapSync));
+    r.snapSync = n;
   }
   r.cd(CD_SNAPLEN) = n;
   r.flags = (r.flags | F_SNAPHAS) & ~F_SNAPEXT;
@@ -295,8 +296,8 @@ __device__ static inline void make_peer(LN &r, const Rows &lg, const Rows &sn, i
     r.term = r.cd(CD_SNAPTERM); r.vote = r.cd(CD_SNAPVOTE);
     int n = r.cd(CD_SNAPLEN);
     if (r.has(F_SNAPEXT))
-      for (int i = r.cd(CD_SNAPSYNC); i < n; i++) { *lg.termp(i, col) = *sn.termp(i, col); *lg.cmdp(i, col) = *sn.cmdp(i, col); }
-    if (n > r.cd(CD_SNAPSYNC)) r.cd(CD_SNAPSYNC) = n;
+      for (int i = r.snapSync; i < n; i++) { *lg.termp(i, col) = *sn.termp(i, col); *lg.cmdp(i, col) = *sn.cmdp(i, col); }
+    if (n > r.snapSync) r.snapSync = n;
     r.logLen = n;
     persist(r, L, w);                     // raft.go:147 runs with commitIndex still 0
     r.commit = r.logLen - 1;              // raft.go:148
@@ -320,7 +321,7 @@ __device__ static inline int start_cmd(LN &r, const Rows &lg, const Rows &sn, in
   int idx = r.logLen;
   *lg.termp(idx, col) = r.term;
   *lg.cmdp(idx, col) = cmd;
-  if (idx < r.cd(CD_SNAPSYNC)) r.cd(CD_SNAPSYNC) = idx;
+  if (idx < r.snapSync) r.snapSync = idx;
   r.logLen = idx + 1;
   r.cd(CD_LASTTERM) = r.term;
   if (idx == r.commit) r.cd(CD_CTERM) = r.term;       // only when commitIndex already ran past the log
