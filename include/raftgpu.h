@@ -241,7 +241,7 @@ int rg_step_noalloc(rg_engine *e, int32_t n_ticks);
  * raft.go once for every configuration.  What rg_create fixed -- peers, log capacity, the net's rates, the
  * parameters of the client, partition and churn schedules, byte accounting -- becomes a compile-time constant
  * of a kernel built at run time (hiprtc, about a second) from the device sources embedded in the library;
- * rg_step then launches it in place of the generic instantiation.  Same code, same results, about 6 % less
+ * rg_step then launches it in place of the generic instantiation.  Same code, same results, 3-9 % less
  * time on large engines (fewer scalar registers, folded arithmetic).  A later change of what was compiled in
  * (rg_set_unreliable, an apply ring, a schedule or per-group rates appearing) rebuilds the kernel at the next
  * rg_step; rg_step_noalloc only uses a kernel that is already built and fits.  RG_ERR_STATE: hiprtc could not be
