@@ -149,7 +149,7 @@ __device__ static inline int turn_start(u64 key, int tick, int P) {
 // whole block.  EXT: the extended instantiation, with wire-byte accounting (rg_config.account_bytes) and the
 // apply ring (rg_config.apply_ring_cap) compiled in; the plain instantiation carries none of it.  LEAN: the
 // instantiation for engines without churn and with the first-leader Start mode (the benchmark's), with that code left out
-// (17 instead of 25 spilled registers).  w: the calling wave's counters of the launch.  stIn / stOut: the set's group words as the
+// (fewer registers to keep alive).  w: the calling wave's counters of the launch.  stIn / stOut: the set's group words as the
 // previous span left them / for the next span, when spans of one launch run on different blocks (else null).
 //
 // DUE: the span of a due launch (k_tick_due).  `set` is then the first group of the calling WAVE's window, dueSlot the
