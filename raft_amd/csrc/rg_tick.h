@@ -154,10 +154,11 @@ __device__ static inline int turn_start(u64 key, int tick, int P) {
 //
 // DUE: the span of a due launch (k_tick_due).  `set` is then the first group of the calling WAVE's window, dueSlot the
 // lane's group as an offset from it and dueValid whether the lane has a group at all; waves of a block work through
-// different numbers of such spans, so nothing in here may wait for the block.
+// different numbers of such spans, so nothing in here may wait for the block.  dueWake: the group's wake word as the block
+// read it when it looked for its due groups (nobody else runs the group in this launch).
 template <int P, bool EXT, bool LEAN, bool COLS, bool DUE = false>
 __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, const DevCfg &c, const int set, const int t0, const int nticks, WaveCtr *w,
-                                          const int *stIn, int *stOut, const int dueSlot = 0, const bool dueValid = false) {
+                                          const int *stIn, int *stOut, const int dueSlot = 0, const bool dueValid = false, const int dueWake = 0) {
   constexpr int PP = P <= 4 ? 4 : 8;        // stride of a group in the per-peer arrays and matrices in memory
   constexpr int NONE = 8;                   // "no such peer" for first-set-bit results
   constexpr int GPB = 4 * GrpN<P>::GWMAX;   // most groups of a 256-thread block
@@ -282,6 +283,25 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   // stores to words another lane may read later are drained (vmcnt) only right before such a read
   bool storesPending = false;
 #define SYNC_STORES() do { if (storesPending) { SECTION_COUNT(w, 7); wave_fence(); storesPending = false; } } while (0)
+  // A span of a due launch meets empty rings and no cached matrix words, and its one or two passes would fetch them from
+  // HBM one after the other in the middle of a round (the leader's words for this lane, the term at PrevLogIndex, the
+  // entries).  Here they are asked for up front instead, all in one trip that the rest of the set-up overlaps: the words
+  // the group's (first) leader keeps for this lane -- only the lane itself ever writes them -- and the last RING entries
+  // of the lane's own log, which go into its ring right before the first pass.
+  int pfTerm[RING]; u64 pfCmd[RING];
+  bool pfLive = false;
+  if constexpr (DUE) {
+    pfLive = valid && !r.has(F_DEAD);
+    const unsigned lm = G.ballot(pfLive && r.isLeader());
+    const int s0 = lm ? (__ffs((int)lm) - 1) : 0;
+    if (pfLive && lm != 0 && peer != s0) { cNext = nextRow(s0 * PP + peer); cMatch = matchRow(s0 * PP + peer); cOwner = s0; }
+#pragma unroll
+    for (int q = 0; q < RING; q++) {
+      const int i = r.logLen - 1 - q;
+      pfTerm[q] = 0; pfCmd[q] = 0;
+      if (pfLive && i >= 0) { pfTerm[q] = *lg.termp(i, peer); pfCmd[q] = *lg.cmdp(i, peer); }
+    }
+  }
   // Groups never exchange anything, so a wave need not keep its groups at the same tick.  Every group has its own
   // clock tg: the next tick at which one of its peers or its control schedule has something to do.  One pass of
   // the loop below advances every unfinished group of the wave through ITS next such tick; ticks in which a
@@ -471,11 +491,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
           if (startNow && mAll && wIdx < NONE && take < due) gNextStart -= (due - take) * c.startPeriod;   // the rest goes round again
           if (cand && peer < wIdx) (void)start_cmd(r, lg, sn, peer, L, 0, gfl, w);            // full log: refused and flagged
           const bool lead = cand && peer == wIdx && take > 0;
-#ifdef RG_NO_BATCHED_STARTS
-          if (true) {
-#else
           if (wave_any(lead && r.commit >= r.logLen)) {        // a commitIndex that ran past the log: entry by entry
-#endif
             if (lead) {
               for (int j = 0; j < take; j++) {
                 u64 cmd = stream_hash(key, STREAM_CMD, 0, (unsigned)(gStartSeq + j));
@@ -523,11 +539,16 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
   if constexpr (DUE) {
     // The wake word is the tick the group's last span was going to run next, so the launches continue exactly as one long
     // launch would have; only a group the host has touched since (wake 0) has to look again.
-    const int wk = valid ? RG_WAKE(*Sp, gq) : 1;
+    const int wk = valid ? dueWake : 1;
     tg = wk > t0 ? wk : t0;
     if (wave_any(wk == 0)) { const int ne = next_event(t0); if (wk == 0) tg = ne; }
   } else tg = next_event(t0);
   if (!valid) tg = 0x7fffffff;
+  if constexpr (DUE) {
+    const int len0 = r.logLen;               // (nothing above appends to a log: set-up only)
+#pragma unroll
+    for (int q = 0; q < RING; q++) { const int i = len0 - 1 - q; if (pfLive && i >= 0) RING_PUSH(i, pfTerm[q], pfCmd[q]); }
+  }
   DSTAMP(3);
   if (wave_any(tg < tEnd)) do {
     const bool run = tg < tEnd;            // the lane's group runs its tick tg in this pass
@@ -547,11 +568,7 @@ __device__ __forceinline__ void tick_span(const DevPtrs *Sp, const HotPtrs &H, c
     // the tester -- and needs no such call.
     bool schedNow = false;
     if constexpr (EXT) schedNow = H.schedN > 0 && run && valid && gSchedPos < H.schedN && H.sched[gSchedPos].tick <= t;
-#ifdef RG_EARLY_STARTS_PART
-    if ((c.partPeriod > 0 || (!LEAN && c.churnPeriod > 0) || EXT) && wave_any(partNow || churnNow || schedNow)) client_starts(run, (partNow || churnNow || schedNow) ? t - 1 : t);
-#else
     if (((!LEAN && c.churnPeriod > 0) || EXT) && wave_any(churnNow || schedNow)) client_starts(run, (churnNow || schedNow) ? t - 1 : t);
-#endif
     STAMP(12);
     if constexpr (EXT) {
       // ---- 0. the scenario schedule: the tester's verbs, by every group on its own peers (config.go:99-278, 302-332, 430-477)
@@ -1385,6 +1402,7 @@ __device__ __forceinline__ void due_launch(const DevPtrs *Sp, const HotPtrs &H, 
   __shared__ WaveCtr dctr[4];
   __shared__ int pick[256];
   __shared__ int waveDue[4];
+  __shared__ int wakeOf[256];
   const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
   WaveCtr *w = &dctr[wave];
   if (lane < RG_WAVE_CTR_SLOTS) w->c[lane] = 0;
@@ -1400,6 +1418,7 @@ __device__ __forceinline__ void due_launch(const DevPtrs *Sp, const HotPtrs &H, 
   if (i < c.dueWin && first + i < c.G) {
     const u64 pr = *(const u64 *)&RG_WAKE(*Sp, first + i);
     due = (int)(unsigned)pr < tEnd || (int)(unsigned)(pr >> 32) == tEnd;
+    wakeOf[i] = (int)(unsigned)pr;
   }
   const u64 m = __builtin_amdgcn_ballot_w64(due);
   if (lane == 0) waveDue[wave] = (int)__builtin_popcountll(m);
@@ -1417,7 +1436,7 @@ __device__ __forceinline__ void due_launch(const DevPtrs *Sp, const HotPtrs &H, 
     const int k = lo + lane / P;
     const bool v = lane / P < GWMAX && k < hi;
     const int off = pick[v ? k : lo];                              // lanes without a group look at the wave's first one and store nothing
-    tick_span<P, EXT, LEAN, COLS, true>(Sp, H, c, (int)first, t0, nticks, w, nullptr, nullptr, off, v);
+    tick_span<P, EXT, LEAN, COLS, true>(Sp, H, c, (int)first, t0, nticks, w, nullptr, nullptr, off, v, wakeOf[off]);
   }
   __syncthreads();
   if (lane < RG_WAVE_CTR_SLOTS && w->c[lane]) atomicAdd((unsigned long long *)&Sp->counters[lane], (unsigned long long)w->c[lane]);
