@@ -216,7 +216,7 @@ int rg_set_stream(rg_engine *e, void *hip_stream);
  * loop :387-530, handlers :200-321, apply :672-688, persist :107-123) in ONE
  * kernel launch; state stays resident in HBM between calls.  Asynchronous on
  * the engine's stream; rg_sync waits.
- * A call of at most 8 ticks (the tester's way of driving an instance: one tick at a time, verbs in between) only runs
+ * A call of at most 12 ticks (the tester's way of driving an instance: one tick at a time, verbs in between) only runs
  * the groups that have something to do inside those ticks -- every group's next such tick is kept next to its state
  * -- and leaves the others alone: groups whose peers are all crashed (slots waiting for a config) cost 4 bytes of
  * reading each.  What the untouched groups would have done meanwhile changes nothing but their own wake-up times (and,

@@ -72,10 +72,10 @@ static int scratch_of(int device, int **out) {
 
 // ---------------------------------------------------------------- host side
 // Launches of at most this many ticks run only the groups that are due (k_tick_due).  Measured on 65,536 five-peer groups
-// of the benchmark workload, kernel time of a launch of 1 / 4 / 8 / 12 / 16 ticks: 108 / 150 / 176 / 187 / 209 us full, 47.5 /
-// 88 / 147 / 190 / 226 us due (a sixth of the groups is due in one tick, nearly all of them in twelve).
+// of the benchmark workload, kernel time of a launch of 1 / 4 / 8 / 12 / 16 / 20 ticks: 103 / 142 / 166 / 180 / 188 / 203 us full,
+// 42 / 76 / 117 / 150 / 183 / 212 us due (a sixth of the groups is due in one tick, nearly all of them in twelve).
 #ifndef RG_DUE_MAX_TICKS
-#define RG_DUE_MAX_TICKS 8
+#define RG_DUE_MAX_TICKS 12
 #endif
 struct rg_engine {
   rg_config cfg;

@@ -1409,8 +1409,11 @@ __device__ __forceinline__ void due_launch(const DevPtrs *Sp, const HotPtrs &H, 
   // c.dueSplit blocks share a window: block r of them takes rounds r, r + c.dueSplit, ...  In a one-tick launch of the
   // benchmark workload a window has 41 +- 6 due groups, one round of 48 for most blocks; the second block of a window runs
   // the surplus of the others at the same time instead of after it (and ends at once when there is none).
-  const long long first = (long long)((int)blockIdx.x / c.dueSplit) * c.dueWin;        // the window's first group
-  const int share = (int)blockIdx.x % c.dueSplit;
+  // (the windows' first blocks come first in the grid, their further blocks after them: consecutive blocks go to different
+  // XCDs in turn, and with a window's two blocks next to each other every other XCD would get nothing but second blocks)
+  const int nWin = (int)gridDim.x / c.dueSplit;
+  const long long first = (long long)((int)blockIdx.x % nWin) * c.dueWin;        // the window's first group
+  const int share = (int)blockIdx.x / nWin;
   const int tEnd = t0 + nticks;
   const int i = (int)threadIdx.x;
   // due when the launch began: not run yet and waking inside it, or already run by another block of this launch

@@ -45,7 +45,7 @@ def test_runs_of_due_launches_between_reads(monkeypatch, capfd, kw, groups, wind
     o, e = _pair(n_groups=groups, **kw)
     rng = random.Random(groups)
     t = 0
-    for stretch in ([1] * 40, [2, 3, 1, 5, 8, 1, 1, 4] * 6, [300], [1] * 25 + [700] + [7] * 9, [1] * 120):
+    for stretch in ([1] * 40, [2, 3, 1, 5, 8, 1, 12, 4] * 6, [300], [1] * 25 + [700] + [7] * 9 + [10, 13, 11], [1] * 120):
         for n in stretch:
             e.step(n)
             t += n
@@ -107,7 +107,7 @@ def test_host_verbs_between_due_launches(monkeypatch, capfd):
                     want = r
                 else:
                     assert r == want, (verb, g, p)
-        n = rng.choice([1, 1, 1, 2, 8])
+        n = rng.choice([1, 1, 1, 2, 8, 12])
         o.step(n)
         e.step(n)
     tr = _trace(capfd)
