@@ -315,7 +315,7 @@ def main():
             "measured_peak": HBM_MEASURED_PEAK_GBS, "frac_of_measured_peak": achieved / HBM_MEASURED_PEAK_GBS,
             "mode": ("fused: peer scalars stay in registers and LDS within a launch of %d ticks (cut into relay chunks of "
                      "at least 1,000 ticks, at most 12, when the groups exceed what the chip holds at once)" % launch) if launch > 1
-                    else "streamed: one launch per tick; a launch runs only the groups with an event in that tick (due launch), the others' state stays in HBM untouched",
+                    else "streamed: one launch per tick; a launch runs only the groups with an event in that tick (due launch), the others' state stays in HBM untouched; kernel_ms: one launch in 16 is timed (its two event packets included, so it lies above the wall time per launch)",
         },
         "safety_flags": flags, "flagged_groups": flagged_groups,
         # the flags are raised by the reference's own rules under partitions (tests/test_repaired_rules.py: with its vote

@@ -253,7 +253,9 @@ int rg_specialize(rg_engine *e);
 int rg_sync(rg_engine *e);
 int rg_now(rg_engine *e, int64_t *tick);
 /* Wall time (ms) of the kernels launched by rg_step so far, from HIP events
- * recorded on the launch stream, and the number of launches.  Synchronises. */
+ * recorded on the launch stream, and the number of launches.  Synchronises.
+ * The two events around a launch cost the stream about 8 us; of the launches of at most 12 ticks (above) one in 16 is
+ * timed and counted for the untimed ones before it (RAFTGPU_DUE_TIME_EVERY=1 in the environment: every one). */
 int rg_step_time_ms(rg_engine *e, double *total_ms, int64_t *launches);
 
 /* Start (raft.go:344-364): index/term/is_leader as the reference returns them. */

@@ -136,3 +136,25 @@ def test_parked_groups_cost_nothing(monkeypatch, capfd):
     assert not d, "; ".join(d[:6])
     lead = o.read("state")[live]
     assert (lead == 2).any(axis=1).all()                # the live groups elected leaders meanwhile
+
+
+def test_step_time_of_sampled_due_launches(monkeypatch):
+    """Of the due launches one in 16 is timed and stands for the others: the launch count stays exact, and the time
+    reported is close to what timing every launch reports (same workload, two engines)."""
+    from raft_amd import Engine
+    kw = dict(n_groups=20000, **LOSSY)
+    monkeypatch.setenv("RAFTGPU_DUE_TIME_EVERY", "1")
+    every = Engine(_abi.make_config(**kw))
+    monkeypatch.delenv("RAFTGPU_DUE_TIME_EVERY")
+    sampled = Engine(_abi.make_config(**kw))
+    res = []
+    for e in (every, sampled):
+        e.step(500)
+        ms0, n0 = e.step_time_ms()
+        for _ in range(403):
+            e.step(1)
+        ms1, n1 = e.step_time_ms()
+        assert n1 - n0 == 403
+        res.append((ms1 - ms0) / 403)
+    assert np.array_equal(every.state_hash(), sampled.state_hash())
+    assert 0.6 * res[0] < res[1] < 1.4 * res[0], res
