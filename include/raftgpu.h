@@ -207,7 +207,10 @@ const char *rg_strerror(int status);
 /* Make (raft.go:700-731) for every peer of every group, all connected, tick 0. */
 int rg_create(const rg_config *cfg, rg_engine **out);
 int rg_destroy(rg_engine *e);
-/* Back to the state rg_create leaves (tick 0, empty persisters), same config. */
+/* Back to the state rg_create leaves (tick 0, empty persisters), same config.  Log entries beyond a log's length and
+ * tester records beyond the group's highest recorded index keep what the run before left in them (a Go slice has no
+ * such elements; nothing in the engine reads them before they are written again): raw dumps of those arrays
+ * (rg_read_state) are meaningful up to the lengths only. */
 int rg_reset(rg_engine *e);
 /* Launch on a caller-owned HIP stream (hipStream_t), NULL = the engine's own. */
 int rg_set_stream(rg_engine *e, void *hip_stream);

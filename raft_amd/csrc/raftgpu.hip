@@ -264,15 +264,20 @@ static void fill_devcfg(rg_engine *e) {
 }
 
 // Make for every peer: one kernel for the per-peer and per-group words, memsets for the rows.
-static int init_state(rg_engine *e) {
+// fresh: the arrays come straight from hipMalloc.  A reset leaves the log rows, snapshot rows and tester records as they
+// are but for every log's entry 0: nothing reads a log beyond its length or a record beyond the group's highest recorded
+// index before it has been written again (4.5 GB less to write for 65,536 five-peer groups with 1,024-entry logs: 0.8 ms).
+static int init_state(rg_engine *e, bool fresh) {
   const long long nL = e->nLanes;
   DevPtrs &S = e->S;
   hipStream_t st = e->stream;
+  if (fresh) {
+    HIPCHK(hipMemsetAsync(S.logRows, 0, (size_t)e->G * e->groupBytes, st));
+    if (S.snapRows) HIPCHK(hipMemsetAsync(S.snapRows, 0, (size_t)e->G * e->groupBytes, st));
+    HIPCHK(hipMemsetAsync(S.applyRec, 0, (size_t)e->G * e->L * 8, st));
+  }
   hipLaunchKernelGGL(k_init, dim3((unsigned)((nL + 255) / 256)), dim3(256), 0, st, S, e->dc, e->PP, nL);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemsetAsync(S.logRows, 0, (size_t)e->G * e->groupBytes, st));
-  if (S.snapRows) HIPCHK(hipMemsetAsync(S.snapRows, 0, (size_t)e->G * e->groupBytes, st));
-  HIPCHK(hipMemsetAsync(S.applyRec, 0, (size_t)e->G * e->L * 8, st));
   HIPCHK(hipMemsetAsync(S.counters, 0, RG_CTR_SLOTS * 8, st));
   HIPCHK(hipMemsetAsync(S.flagSummary, 0, 8, st));
   if (e->applyCap > 0) HIPCHK(hipMemsetAsync(e->applyHead, 0, (size_t)e->nLanes * sizeof(unsigned), st));
@@ -386,7 +391,7 @@ extern "C" int rg_create(const rg_config *cfg, rg_engine **out) {
   e->H.applyRing = e->applyRing; e->H.applyHead = e->applyHead; e->H.applyCap = e->applyCap; e->H.netCfg = nullptr; e->H.sched = nullptr; e->H.schedN = 0;
   e->H.logRows = S.logRows; e->H.snapRows = S.snapRows; e->H.nextIdx = S.nextIdx; e->H.matchIdx = S.matchIdx; e->H.applyRec = S.applyRec;
   if (dalloc(e, &e->dS, 1) != RG_OK || hipMemcpy(e->dS, &e->S, sizeof(DevPtrs), hipMemcpyHostToDevice) != hipSuccess) { free_engine(e); return RG_ERR_NOMEM; }
-  rc = init_state(e);
+  rc = init_state(e, true);
   if (rc != RG_OK) { free_engine(e); return rc; }
   { const char *v = getenv("RAFTGPU_SPECIALIZE"); e->specWanted = v && atoi(v) > 0; }   // as rg_specialize, compiled at the first launch
   *out = e;
@@ -421,7 +426,7 @@ extern "C" int rg_reset(rg_engine *e) {
   HIPCHK(hipStreamSynchronize(e->stream));
   int rc = collect_events(e);
   if (rc != RG_OK) return rc;
-  return init_state(e);
+  return init_state(e, false);
 }
 
 extern "C" int rg_set_stream(rg_engine *e, void *s) {

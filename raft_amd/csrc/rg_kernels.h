@@ -193,6 +193,11 @@ __global__ void k_init(DevPtrs S, DevCfg c, int PP, long long nLanes) {
   long long gl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gl >= nLanes) return;
   init_lane(S, c, PP, gl, 0);
+  const int g = (int)(gl / PP), p = (int)(gl % PP);
+  if (g < c.G && p < c.P) {                    // logs[0], the entry every log begins with (raft.go:710-715)
+    const Rows lg = rows_of(S.logRows, c, g);
+    *lg.termp(0, p) = 0; *lg.cmdp(0, p) = 0;
+  }
 }
 
 // A fresh set of peers (config.go:60-96: a new tester config) in each listed group at tick nowTick: one block per
