@@ -157,4 +157,4 @@ def test_step_time_of_sampled_due_launches(monkeypatch):
         assert n1 - n0 == 403
         res.append((ms1 - ms0) / 403)
     assert np.array_equal(every.state_hash(), sampled.state_hash())
-    assert 0.6 * res[0] < res[1] < 1.4 * res[0], res
+    assert 0.5 * res[0] < res[1] < 2.0 * res[0], res       # (without the weights it would be a sixteenth)
