@@ -1406,6 +1406,20 @@ __device__ __forceinline__ void due_launch(const DevPtrs *Sp, const HotPtrs &H, 
   const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
   WaveCtr *w = &dctr[wave];
   if (lane < RG_WAVE_CTR_SLOTS) w->c[lane] = 0;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RG_NO_KERNARG_TOUCH)   // (device pass only: the host pass cannot parse the constraints)
+  // The kernel's arguments are some 550 bytes that the compiler fetches where they are first used -- most of them at the
+  // start of the first span, a trip to memory of their own.  One word of each of their 64-byte lines is asked for here,
+  // so the lines arrive in the scalar cache while the wake words are on their way.
+  int ka0, ka1, ka2, ka3, ka4, ka5, ka6, ka7, ka8;
+  {
+    static_assert(sizeof(DevPtrs) + sizeof(HotPtrs) + sizeof(DevCfg) >= 0x204, "the touched lines lie inside the arguments");
+    const void *ka = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("s_load_dword %0, %9, 0x0\n\ts_load_dword %1, %9, 0x40\n\ts_load_dword %2, %9, 0x80\n\ts_load_dword %3, %9, 0xc0\n\t"
+                 "s_load_dword %4, %9, 0x100\n\ts_load_dword %5, %9, 0x140\n\ts_load_dword %6, %9, 0x180\n\ts_load_dword %7, %9, 0x1c0\n\t"
+                 "s_load_dword %8, %9, 0x200"
+                 : "=&s"(ka0), "=&s"(ka1), "=&s"(ka2), "=&s"(ka3), "=&s"(ka4), "=&s"(ka5), "=&s"(ka6), "=&s"(ka7), "=&s"(ka8) : "s"(ka));
+  }
+#endif
   // c.dueSplit blocks share a window: block r of them takes rounds r, r + c.dueSplit, ...  In a one-tick launch of the
   // benchmark workload a window has 41 +- 6 due groups, one round of 48 for most blocks; the second block of a window runs
   // the surplus of the others at the same time instead of after it (and ends at once when there is none).
@@ -1425,6 +1439,10 @@ __device__ __forceinline__ void due_launch(const DevPtrs *Sp, const HotPtrs &H, 
   }
   const u64 m = __builtin_amdgcn_ballot_w64(due);
   if (lane == 0) waveDue[wave] = (int)__builtin_popcountll(m);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RG_NO_KERNARG_TOUCH)   // (device pass only: the host pass cannot parse the constraints)
+  // (the registers stay reserved until the words have arrived)
+  asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(ka0), "s"(ka1), "s"(ka2), "s"(ka3), "s"(ka4), "s"(ka5), "s"(ka6), "s"(ka7), "s"(ka8));
+#endif
   __syncthreads();
   int before = 0, nDue = 0;
 #pragma unroll
